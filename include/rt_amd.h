@@ -1,0 +1,265 @@
+/*
+ * rt_amd.h -- C ABI of the MI355X rendering hot path.
+ *
+ * The reference has no plugin/FFI layer; its seam for this path is the free
+ * function renderImage (src/render.h:34) plus the virtual BVHInterface
+ * (src/bvh_interface.h:12-72).  Each entry point below names the reference
+ * interface it stands in for.  Only plain pointers, sizes and POD structs
+ * cross this boundary; the library owns all device memory.
+ *
+ * Conventions: every call returns 0 on success and a negative rt_status on
+ * failure; rt_last_error() returns the message of the last failure on that
+ * context (or of the last context-less failure when ctx is NULL).  Calls on
+ * one context must be serialised by the caller; one context drives one GPU.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument / malformed BVH */
+    RT_ERR_UNSUPPORTED = -2, /* feature outside this path (motion blur, bloom, SAH build) */
+    RT_ERR_DEVICE = -3,      /* HIP runtime failure */
+    RT_ERR_STATE = -4        /* call order (render before scene upload, ...) */
+};
+
+/* Vertex, framework/include/framework/mesh.h:14-20 (32 B) */
+typedef struct {
+    float position[3];
+    float normal[3];
+    float texCoord[2];
+} rt_vertex;
+
+/* BVHInterface::Primitive, src/bvh_interface.h:14-23 (100 B) */
+typedef struct {
+    uint32_t meshID;
+    rt_vertex v0, v1, v2;
+} rt_primitive;
+
+/* BVHInterface::Node, src/bvh_interface.h:28-54 (32 B): inner {left,right},
+ * leaf {RT_LEAF_BIT|offset, count}. */
+#define RT_LEAF_BIT 0x80000000u
+typedef struct {
+    float lower[3];
+    float upper[3];
+    uint32_t data[2];
+} rt_node;
+
+/* Material, framework/include/framework/mesh.h:22-34; kdTexture indexes the
+ * image table passed to rt_scene_upload, -1 = none. */
+typedef struct {
+    float kd[3];
+    float ks[3];
+    float shininess;
+    float transparency;
+    int32_t kdTexture;
+} rt_material;
+
+/* Image, framework/include/framework/image.h:14-24: row-major RGB floats. */
+typedef struct {
+    const float* pixels;
+    int32_t width;
+    int32_t height;
+} rt_image;
+
+/* Sphere, src/common.h:39-43 */
+typedef struct {
+    float center[3];
+    float radius;
+    rt_material material;
+} rt_sphere;
+
+/* PointLight / SegmentLight / ParallelogramLight, src/common.h:45-60.
+ * type 0: v = position, color.  type 1: endpoint0, endpoint1, color0, color1.
+ * type 2: v0, edge01, edge02, color0, color1, color2, color3. */
+typedef struct {
+    int32_t type;
+    float v[21];
+} rt_light;
+
+/* Features + ExtraFeatures, src/common.h:62-106, one field per member in
+ * declaration order.  maxRayDepth: the reference hard-codes `rayDepth < 6`
+ * (src/recursive.cpp:43); 6 reproduces it, at most 7 is accepted. */
+typedef struct {
+    int32_t enableShading;
+    int32_t enableReflections;
+    int32_t enableShadows;
+    int32_t enableNormalInterp;
+    int32_t enableTextureMapping;
+    int32_t enableAccelStructure;
+    int32_t enableBilinearTextureFiltering;
+    int32_t enableTransparency;
+    int32_t enableJitteredSampling;
+    int32_t shadingModel;
+    uint32_t numPixelSamples;
+    uint32_t numShadowSamples;
+    int32_t enableBvhSahBinning;
+    int32_t enableBloomEffect;
+    int32_t enableDepthOfField;
+    int32_t enableEnvironmentMap;
+    int32_t enableGlossyReflection;
+    int32_t enableMipmapTextureFiltering;
+    int32_t enableMotionBlur;
+    int32_t motionBlurSamples;
+    float movement;
+    uint32_t numGlossySamples;
+    float glossyExponent;
+    uint32_t bloomFilterSize;
+    float bloomThreshold;
+    float depthOfFieldDistance;
+    float depthOfFieldCircleDiameter;
+    uint32_t numDepthOfFieldSamples;
+    int32_t maxRayDepth;
+} rt_features;
+
+/* Trackball state, framework/src/trackball.cpp:23-31,64-69: angles in
+ * radians, aspect = window width / height (framework/src/window.cpp:413-418). */
+typedef struct {
+    float lookAt[3];
+    float rotation[3];
+    float distance;
+    float fovy;
+    float aspect;
+} rt_camera;
+
+/* Ray, framework/include/framework/ray.h:9-13 */
+typedef struct {
+    float origin[3];
+    float direction[3];
+    float t;
+} rt_ray;
+
+/* What BVHInterface::intersect leaves behind (src/bvh_interface.h:61): the
+ * bool result, ray.t, and the HitInfo fields (src/common.h:22-27), with the
+ * material given as its slot (mesh id, or n_meshes + sphere index) and the
+ * index into primitives() of the accepted hit (-1 for none / a sphere). */
+typedef struct {
+    int32_t hit;
+    float t;
+    int32_t primitive;
+    int32_t material;
+    float normal[3];
+    float barycentricCoord[3];
+    float texCoord[2];
+} rt_hit;
+
+typedef struct {
+    uint64_t rays;        /* BVHInterface::intersect invocations */
+    uint64_t inner_nodes; /* sibling-pair records fetched (0 unless collected) */
+    uint64_t tri_tests;   /* triangle records tested   (0 unless collected) */
+    float kernel_ms;      /* device time of the render kernel, HIP events */
+    float total_ms;       /* wall time of the call */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Context on one HIP device.  No reference counterpart (the reference is a
+ * single-process CPU program); it owns what `Scene`/`BVH` own there. */
+int rt_ctx_create(int device_ordinal, rt_ctx** out);
+void rt_ctx_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* BVH::BVH(scene, features), src/bvh.cpp:52-101 with buildRecursive
+ * (:424-493) and the median split (:208-223); host code.  prims_in is the
+ * scene-order primitive list (:66-77).  nodes_out needs max(2, 2*n) entries,
+ * prims_out n entries.  sah_binning != 0 -> RT_ERR_UNSUPPORTED. */
+int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_node* nodes_out,
+                 rt_primitive* prims_out, uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves);
+
+/* Hands the library what renderImage reads through `scene` and `bvh`
+ * (src/render.h:17-26): bvh.nodes(), bvh.primitives() (src/bvh_interface.h:64-67),
+ * scene.meshes[i].material, the textures they name, the six
+ * environmentMapTextures (src/scene.h:40-48; image index or -1) and
+ * scene.spheres.  All host memory stays caller-owned and is copied; the
+ * device layout is built here.  generation (optional) receives a counter that
+ * changes with every upload. */
+int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const rt_primitive* prims,
+                    uint32_t n_prims, const rt_material* mesh_materials, uint32_t n_meshes,
+                    const rt_image* images, uint32_t n_images, const int32_t env_faces[6],
+                    const rt_sphere* spheres, uint32_t n_spheres, uint64_t* generation);
+
+/* scene.lights (src/scene.h:36) and the Features argument of renderImage;
+ * cheap, may be re-sent before every frame (the GUI mutates both between
+ * calls, src/main.cpp:179-270,340-418). */
+int rt_lights_set(rt_ctx* ctx, const rt_light* lights, uint32_t n);
+int rt_features_set(rt_ctx* ctx, const rt_features* features);
+
+/* renderImage(scene, bvh, features, camera, screen), src/render.cpp:19-51,
+ * including the depth-of-field variant (src/extra.cpp:89-113).  Synchronous.
+ * out_rgb (host) receives width*height*3 floats in Screen order, index
+ * (height-1-y)*width + x (src/screen.cpp:36-42).  stats may be NULL. */
+int rt_render(rt_ctx* ctx, const rt_camera* camera, int width, int height, float* out_rgb, rt_stats* stats);
+
+/* Same frame, device-resident and sharded by interleaved 8x8 pixel tiles:
+ * tile k (row-major over ceil(width/8) x ceil(height/8)) belongs to shard
+ * k % shard_count.  With shard_count == 1 d_out is the whole frame in Screen
+ * order (width*height*3 floats); otherwise it is this shard's packed tiles,
+ * rt_shard_floats() floats.  The kernel is enqueued on `stream` (a
+ * hipStream_t, NULL = default stream) and the call returns without waiting;
+ * collect_stats != 0 makes it wait and fill *stats including node/triangle
+ * counters.  No reference counterpart: pixels are independent there
+ * (src/render.cpp:34-42), which is what makes the split legal. */
+int rt_render_device(rt_ctx* ctx, const rt_camera* camera, int width, int height, int shard_index,
+                     int shard_count, void* d_out, size_t d_out_floats, void* stream,
+                     int collect_stats, rt_stats* stats);
+size_t rt_shard_floats(int width, int height, int shard_index, int shard_count);
+
+/* Scatter shard_count packed tile buffers (as laid end to end by a gather,
+ * each rt_shard_floats(.., 0, shard_count) floats apart) into a frame in
+ * Screen order.  Device pointers; enqueued on `stream`. */
+int rt_deinterleave(rt_ctx* ctx, const void* d_packed, int width, int height, int shard_count,
+                    void* d_frame, void* stream);
+
+/* Blocks until the work rt_render_device / rt_deinterleave enqueued on
+ * `stream` has finished and returns the ray count of the last render. */
+int rt_sync(rt_ctx* ctx, void* stream, rt_stats* stats);
+
+/* BVHInterface::intersect(state, ray, hitInfo), src/bvh_interface.h:61 ->
+ * intersectRayWithBVH, src/bvh.cpp:337-358, for n rays at once.  rays[i].t is
+ * updated in place like `ray.t`; hits[i] receives the HitInfo.  Uses the
+ * features last set (enableAccelStructure, enableNormalInterp,
+ * enableTextureMapping). */
+int rt_intersect_batch(rt_ctx* ctx, rt_ray* rays, uint32_t n, rt_hit* hits);
+
+/* The unit-tested pure functions, evaluated on the device.  in/out are packed
+ * float records, n of them:
+ *  RT_EVAL_BARYCENTRIC      in v0 v1 v2 p (12)      out bc (3)      src/interpolate.cpp:13-24
+ *  RT_EVAL_INTERP_NORMAL    in n0 n1 n2 bc (12)     out n (3)       src/interpolate.cpp:34-40
+ *  RT_EVAL_INTERP_TEXCOORD  in t0 t1 t2 bc (9)      out uv (2)      src/interpolate.cpp:50-55
+ *  RT_EVAL_TEX_NEAREST      in image, u v (3)       out rgb (3)     src/texture.cpp:12-35
+ *  RT_EVAL_TEX_BILINEAR     in image, u v (3)       out rgb (3)     src/texture.cpp:44-95
+ *  RT_EVAL_SEGMENT_LIGHT    in light, sample (2)    out pos col (6) src/light.cpp:26-36
+ *  RT_EVAL_PARALLELOGRAM    in light, sx sy (3)     out pos col (6) src/light.cpp:60-74
+ *  RT_EVAL_SAMPLER          in seed, count (2, as uint32 bits; n must be 1)
+ *                           out count floats                         src/sampler.h:36-39
+ *  RT_EVAL_CAMERA_RAY       in ndc x y (2)          out o d (6)     framework/src/trackball.cpp:101-110
+ *                           (camera = aux)
+ *  RT_EVAL_SHADING          in material(8: kd ks shininess transparency) normal cameraDir
+ *                           lightDir lightColor (20) out rgb (3)    src/shading.cpp:29-56
+ * "image"/"light" are indices (float-encoded) into the uploaded image table /
+ * the lights last set.  aux is NULL except where noted. */
+enum rt_eval_kind {
+    RT_EVAL_BARYCENTRIC = 0,
+    RT_EVAL_INTERP_NORMAL = 1,
+    RT_EVAL_INTERP_TEXCOORD = 2,
+    RT_EVAL_TEX_NEAREST = 3,
+    RT_EVAL_TEX_BILINEAR = 4,
+    RT_EVAL_SEGMENT_LIGHT = 5,
+    RT_EVAL_PARALLELOGRAM = 6,
+    RT_EVAL_SAMPLER = 7,
+    RT_EVAL_CAMERA_RAY = 8,
+    RT_EVAL_SHADING = 9
+};
+int rt_eval_batch(rt_ctx* ctx, int kind, const float* in, uint32_t n, float* out, const void* aux);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

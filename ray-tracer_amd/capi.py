@@ -1,0 +1,191 @@
+"""ctypes binding of the product library (ray-tracer_amd/librt_amd.so, C ABI in
+include/rt_amd.h).  Fails loudly when the library is missing: there is no CPU
+fallback on the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scene_io as sio
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+# every symbol include/rt_amd.h declares
+EXPORTS = [
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_bvh_build", "rt_scene_upload", "rt_lights_set",
+    "rt_features_set", "rt_render", "rt_render_device", "rt_shard_floats", "rt_deinterleave", "rt_sync",
+    "rt_intersect_batch", "rt_eval_batch",
+]
+
+(EVAL_BARYCENTRIC, EVAL_INTERP_NORMAL, EVAL_INTERP_TEXCOORD, EVAL_TEX_NEAREST, EVAL_TEX_BILINEAR,
+ EVAL_SEGMENT_LIGHT, EVAL_PARALLELOGRAM, EVAL_SAMPLER, EVAL_CAMERA_RAY, EVAL_SHADING) = range(10)
+_EVAL_IN = [12, 12, 9, 3, 3, 2, 3, 2, 2, 20]
+_EVAL_OUT = [3, 3, 2, 3, 3, 6, 6, 0, 6, 3]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rt_amd error {code}: {message}")
+        self.code = code
+
+
+class _Image(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("inner_nodes", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("kernel_ms", C.c_float), ("total_ms", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with ray-tracer_amd/csrc/Makefile "
+                               "(__graft_entry__.build()); the rendering path has no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        l.rt_last_error.restype = C.c_char_p
+        l.rt_last_error.argtypes = [C.c_void_p]
+        l.rt_shard_floats.restype = C.c_size_t
+        l.rt_ctx_destroy.argtypes = [C.c_void_p]
+        l.rt_ctx_destroy.restype = None
+        _lib = l
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def bvh_build(prims: np.ndarray, sah_binning: bool = False):
+    """BVH::BVH(scene, features): returns (nodes, primitives, num_levels, num_leaves)."""
+    prims = np.ascontiguousarray(prims, dtype=sio.PRIMITIVE)
+    n = len(prims)
+    nodes = np.zeros(max(2, 2 * n), dtype=sio.NODE)
+    out = np.zeros(n, dtype=sio.PRIMITIVE)
+    nn, nl, nf = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = lib().rt_bvh_build(_p(prims), C.c_uint32(n), int(sah_binning), _p(nodes), _p(out),
+                            C.byref(nn), C.byref(nl), C.byref(nf))
+    if rc != 0:
+        raise RtError(rc, lib().rt_last_error(None).decode())
+    return nodes[:nn.value].copy(), out, nl.value, nf.value
+
+
+def shard_floats(width, height, shard, n_shard) -> int:
+    return int(lib().rt_shard_floats(width, height, shard, n_shard))
+
+
+class Context:
+    """One rt_ctx on one HIP device."""
+
+    def __init__(self, device: int = 0):
+        self.handle = C.c_void_p()
+        rc = lib().rt_ctx_create(int(device), C.byref(self.handle))
+        if rc != 0:
+            raise RtError(rc, lib().rt_last_error(None).decode())
+        self.nodes = self.prims = None
+        self.num_levels = self.num_leaves = 0
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().rt_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(rc, lib().rt_last_error(self.handle).decode())
+
+    # -- scene ----------------------------------------------------------
+    def upload_scene(self, scene, nodes=None, prims=None):
+        """Build the BVH over `scene` (unless nodes/prims are given), upload it
+        with materials / textures / spheres, and set the scene's lights."""
+        if nodes is None:
+            nodes, prims, self.num_levels, self.num_leaves = bvh_build(scene.primitives())
+        self.nodes = np.ascontiguousarray(nodes, dtype=sio.NODE)
+        self.prims = np.ascontiguousarray(prims, dtype=sio.PRIMITIVE)
+        mats = scene.materials()
+        keep = [np.ascontiguousarray(im, dtype=np.float32) for im in scene.images]
+        imgs = (_Image * max(1, len(keep)))()
+        for i, im in enumerate(keep):
+            imgs[i] = _Image(im.ctypes.data, im.shape[1], im.shape[0])
+        env = (C.c_int32 * 6)(*scene.env_faces)
+        spheres = np.ascontiguousarray(scene.spheres, dtype=sio.SPHERE)
+        gen = C.c_uint64()
+        self._check(lib().rt_scene_upload(
+            self.handle, _p(self.nodes), C.c_uint32(len(self.nodes)), _p(self.prims), C.c_uint32(len(self.prims)),
+            _p(mats), C.c_uint32(len(mats)), imgs, C.c_uint32(len(keep)), env, _p(spheres),
+            C.c_uint32(len(spheres)), C.byref(gen)))
+        self.set_lights(scene.lights_array())
+        return gen.value
+
+    def set_lights(self, lights):
+        lights = np.ascontiguousarray(lights, dtype=sio.LIGHT)
+        self._check(lib().rt_lights_set(self.handle, _p(lights), C.c_uint32(len(lights))))
+
+    def set_features(self, features):
+        f = np.ascontiguousarray(features, dtype=sio.FEATURES)
+        self._check(lib().rt_features_set(self.handle, _p(f)))
+
+    # -- rendering ------------------------------------------------------
+    def render(self, camera, width, height):
+        """renderImage: returns ((H, W, 3) float32 in Screen order, stats dict)."""
+        out = np.zeros((height, width, 3), dtype=np.float32)
+        cam = np.ascontiguousarray(camera, dtype=sio.CAMERA)
+        st = Stats()
+        self._check(lib().rt_render(self.handle, _p(cam), int(width), int(height), _p(out), C.byref(st)))
+        return out, st.as_dict()
+
+    def render_device(self, camera, width, height, d_out_ptr: int, d_out_floats: int, shard=0, n_shard=1,
+                      stream: int = 0, collect_stats=False):
+        cam = np.ascontiguousarray(camera, dtype=sio.CAMERA)
+        st = Stats()
+        self._check(lib().rt_render_device(self.handle, _p(cam), int(width), int(height), int(shard), int(n_shard),
+                                           C.c_void_p(d_out_ptr), C.c_size_t(d_out_floats), C.c_void_p(stream),
+                                           int(bool(collect_stats)), C.byref(st)))
+        return st.as_dict() if collect_stats else None
+
+    def deinterleave(self, d_packed_ptr: int, width, height, n_shard, d_frame_ptr: int, stream: int = 0):
+        self._check(lib().rt_deinterleave(self.handle, C.c_void_p(d_packed_ptr), int(width), int(height), int(n_shard),
+                                          C.c_void_p(d_frame_ptr), C.c_void_p(stream)))
+
+    def sync(self, stream: int = 0):
+        st = Stats()
+        self._check(lib().rt_sync(self.handle, C.c_void_p(stream), C.byref(st)))
+        return st.as_dict()
+
+    # -- BVHInterface::intersect -----------------------------------------
+    def intersect(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=sio.RAY).copy()
+        hits = np.zeros(len(rays), dtype=sio.HIT)
+        self._check(lib().rt_intersect_batch(self.handle, _p(rays), C.c_uint32(len(rays)), _p(hits)))
+        return rays, hits
+
+    # -- unit-tested pure functions ---------------------------------------
+    def eval(self, kind: int, records, aux=None, out_count=None):
+        rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, _EVAL_IN[kind])
+        n = len(rec)
+        width = _EVAL_OUT[kind] if out_count is None else out_count
+        out = np.zeros((n, width), dtype=np.float32)
+        auxp = _p(np.ascontiguousarray(aux)) if aux is not None else None
+        self._check(lib().rt_eval_batch(self.handle, int(kind), _p(rec), C.c_uint32(n), _p(out), auxp))
+        return out
+
+    def sampler_next(self, seed: int, n: int) -> np.ndarray:
+        rec = np.array([seed, n], dtype=np.uint32).view(np.float32)
+        return self.eval(EVAL_SAMPLER, rec, out_count=n)[0]

@@ -1,0 +1,854 @@
+// rt_capi.cpp -- the C ABI of include/rt_amd.h: context, host-side BVH build,
+// flattening of the reference's wire format into the device layout, and the
+// launches.  Built with hipcc (-ffp-contract=off) so the per-triangle
+// constants computed here carry the same roundings as the scalar code they
+// stand in for.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_device.hpp"
+
+namespace rt {
+hipError_t renderOccupancy(int variant, int blockThreads, size_t ldsBytes, int* blocksPerCU);
+hipError_t launchRender(int variant, int blocks, int blockThreads, size_t ldsBytes, hipStream_t stream, const DevScene& sc,
+    const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, DevCounters* ctr, float* out, int minActive, int logicRounds);
+hipError_t launchIntersect(int blockThreads, size_t ldsBytes, hipStream_t stream, const DevScene& sc, const DevFeat& ft,
+    rt_ray* rays, rt_hit* hits, uint32_t n);
+hipError_t launchDeinterleave(hipStream_t stream, const float* packed, float* frame, int width, int height, int tilesX,
+    int tilesY, int nShard, size_t shardStride);
+hipError_t launchEval(hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, int kind,
+    const float* in, float* out, uint32_t n);
+} // namespace rt
+
+using namespace rt;
+
+static thread_local std::string g_lastError;
+
+struct rt_ctx {
+    int device = 0;
+    int numCU = 256;
+    std::string error;
+    // device buffers
+    float4* dPairs = nullptr;
+    float4* dTris = nullptr;
+    float4* dAttrs = nullptr;
+    DevMaterial* dMats = nullptr;
+    DevTex* dTexs = nullptr;
+    float* dTexels = nullptr;
+    DevSphere* dSpheres = nullptr;
+    rt_light* dLights = nullptr;
+    uint32_t lightCap = 0;
+    DevCounters* dCounters = nullptr;
+    float* dFrame = nullptr;
+    size_t frameCap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevScene scene {};
+    bool haveScene = false;
+    uint32_t numLevels = 1;
+    uint64_t generation = 0;
+    rt_features features {};
+    bool haveFeatures = false;
+    // tuning knobs of the render kernel (environment-overridable for experiments)
+    int minActive = 40;
+    int logicRounds = 2;
+    int blocksPerCU = 0; // 0 = ask the occupancy API
+};
+
+static int fail(rt_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->error = buf;
+    g_lastError = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(ctx, RT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+static hipError_t uploadVec(T** dptr, const std::vector<T>& v)
+{
+    if (*dptr) {
+        (void)hipFree(*dptr);
+        *dptr = nullptr;
+    }
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dptr), bytes);
+    if (e != hipSuccess)
+        return e;
+    if (!v.empty())
+        e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+extern "C" {
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_lastError.c_str(); }
+
+int rt_ctx_create(int device_ordinal, rt_ctx** out)
+{
+    if (!out)
+        return fail(nullptr, RT_ERR_INVALID, "rt_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&count));
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return fail(nullptr, RT_ERR_INVALID, "rt_ctx_create: device %d not in [0, %d)", device_ordinal, count);
+    HIP_TRY(nullptr, hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_ordinal));
+    rt_ctx* ctx = new rt_ctx;
+    ctx->device = device_ordinal;
+    ctx->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->dCounters), sizeof(DevCounters)) != hipSuccess
+        || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, RT_ERR_DEVICE, "rt_ctx_create: device allocation failed");
+    }
+    if (const char* s = getenv("RT_AMD_MIN_ACTIVE"))
+        ctx->minActive = atoi(s);
+    if (const char* s = getenv("RT_AMD_LOGIC_ROUNDS"))
+        ctx->logicRounds = std::max(1, atoi(s));
+    if (const char* s = getenv("RT_AMD_BLOCKS_PER_CU"))
+        ctx->blocksPerCU = atoi(s);
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_ctx_destroy(rt_ctx* ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    void* ptrs[] = { ctx->dPairs, ctx->dTris, ctx->dAttrs, ctx->dMats, ctx->dTexs, ctx->dTexels, ctx->dSpheres, ctx->dLights,
+        ctx->dCounters, ctx->dFrame };
+    for (void* p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    if (ctx->ev0)
+        (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1)
+        (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+// ---------------------------------------------------------------------------
+// Host BVH build.  Same tree as BVH::BVH (src/bvh.cpp:52-101, :424-493): leaf
+// at <= 4 primitives, split along the longest axis of the span box at
+// (n+1)/2 after sorting by centroid (:208-223), children allocated left then
+// right, leaves appended in depth-first order (:369-387).  The sort runs on
+// (centroid key, index) pairs with std::sort: the permutation a comparison
+// sort produces depends only on the comparison results, so this is the
+// permutation std::ranges::sort yields on the 100-byte primitives themselves
+// with the same toolchain, ties included, at a fraction of the data movement.
+// ---------------------------------------------------------------------------
+namespace {
+struct BuildPrim {
+    float lo[3], hi[3], c[3];
+};
+struct KeyIdx {
+    float key;
+    uint32_t idx;
+};
+
+struct HostBuilder {
+    const rt_primitive* in;
+    std::vector<BuildPrim> info;
+    std::vector<uint32_t> order; // current arrangement of primitive indices
+    std::vector<KeyIdx> scratch;
+    std::vector<rt_node> nodes;
+    std::vector<uint32_t> outOrder;
+
+    void build(uint32_t begin, uint32_t n, uint32_t nodeIndex)
+    {
+        rt_node node;
+        if (n == 0) { // computeSpanAABB of an empty span: AxisAlignedBox{} (src/bvh.cpp:142-144)
+            for (int a = 0; a < 3; a++)
+                node.lower[a] = 0.0f, node.upper[a] = 1.0f;
+        } else {
+            const BuildPrim& f = info[order[begin]];
+            for (int a = 0; a < 3; a++)
+                node.lower[a] = f.lo[a], node.upper[a] = f.hi[a];
+            for (uint32_t i = 1; i < n; i++) {
+                const BuildPrim& b = info[order[begin + i]];
+                for (int a = 0; a < 3; a++) {
+                    node.lower[a] = std::min(node.lower[a], b.lo[a]);
+                    node.upper[a] = std::max(node.upper[a], b.hi[a]);
+                }
+            }
+        }
+        if (n <= 4) {
+            node.data[0] = static_cast<uint32_t>(outOrder.size()) | RT_LEAF_BIT;
+            node.data[1] = n;
+            for (uint32_t i = 0; i < n; i++)
+                outOrder.push_back(order[begin + i]);
+            nodes[nodeIndex] = node;
+            return;
+        }
+        const float xl = node.upper[0] - node.lower[0], yl = node.upper[1] - node.lower[1], zl = node.upper[2] - node.lower[2];
+        const int axis = (xl >= yl && xl >= zl) ? 0 : (yl >= zl ? 1 : 2); // src/bvh.cpp:183-196
+        scratch.resize(n);
+        for (uint32_t i = 0; i < n; i++)
+            scratch[i] = { info[order[begin + i]].c[axis], order[begin + i] };
+        std::sort(scratch.begin(), scratch.end(), [](const KeyIdx& a, const KeyIdx& b) { return a.key < b.key; });
+        for (uint32_t i = 0; i < n; i++)
+            order[begin + i] = scratch[i].idx;
+        const uint32_t split = (n + 1) / 2;
+        const uint32_t left = static_cast<uint32_t>(nodes.size());
+        nodes.emplace_back();
+        const uint32_t right = static_cast<uint32_t>(nodes.size());
+        nodes.emplace_back();
+        node.data[0] = left;
+        node.data[1] = right;
+        nodes[nodeIndex] = node;
+        build(begin, split, left);
+        build(begin + split, n - split, right);
+    }
+};
+} // namespace
+
+int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_node* nodes_out, rt_primitive* prims_out,
+    uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves)
+{
+    if ((n && !prims_in) || !nodes_out || (n && !prims_out) || !n_nodes || !n_levels || !n_leaves)
+        return fail(nullptr, RT_ERR_INVALID, "rt_bvh_build: NULL argument");
+    if (sah_binning)
+        return fail(nullptr, RT_ERR_UNSUPPORTED, "rt_bvh_build: SAH binning (enableBvhSahBinning) is outside this path");
+    HostBuilder b;
+    b.in = prims_in;
+    b.info.resize(n);
+    b.order.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const rt_primitive& p = prims_in[i];
+        BuildPrim& q = b.info[i];
+        for (int a = 0; a < 3; a++) {
+            const float x = p.v0.position[a], y = p.v1.position[a], z = p.v2.position[a];
+            q.lo[a] = std::min(x, std::min(y, z)); // src/bvh.cpp:117-133
+            q.hi[a] = std::max(x, std::max(y, z));
+            q.c[a] = ((x + y) + z) / 3.0f; // src/bvh.cpp:169-175
+        }
+        b.order[i] = i;
+    }
+    b.nodes.reserve(static_cast<size_t>(n) + 2);
+    b.nodes.emplace_back();
+    b.nodes.emplace_back(); // dummy node 1 keeps sibling pairs adjacent (src/bvh.cpp:88-89)
+    std::memset(&b.nodes[1], 0, sizeof(rt_node));
+    b.nodes[1].upper[0] = b.nodes[1].upper[1] = b.nodes[1].upper[2] = 1.0f;
+    b.outOrder.reserve(n);
+    b.build(0, n, 0);
+    std::copy(b.nodes.begin(), b.nodes.end(), nodes_out);
+    for (uint32_t i = 0; i < n; i++)
+        prims_out[i] = prims_in[b.outOrder[i]];
+    *n_nodes = static_cast<uint32_t>(b.nodes.size());
+    // numLevels / numLeaves, src/bvh.cpp:498-547
+    std::vector<uint32_t> levels(b.nodes.size(), 0);
+    uint32_t numLevels = 1, numLeaves = 0;
+    for (size_t i = 0; i < b.nodes.size(); i++) {
+        if (i == 1)
+            continue;
+        const rt_node& nd = b.nodes[i];
+        if (nd.data[0] & RT_LEAF_BIT) {
+            numLeaves++;
+        } else {
+            levels[nd.data[0]] = levels[i] + 1;
+            levels[nd.data[1]] = levels[i] + 1;
+        }
+    }
+    for (size_t i = 2; i < b.nodes.size(); i++)
+        numLevels = std::max(numLevels, levels[i] + 1);
+    *n_levels = numLevels;
+    *n_leaves = numLeaves;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Scene upload: validate the wire-format BVH, then flatten it.
+// ---------------------------------------------------------------------------
+int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const rt_primitive* prims, uint32_t n_prims,
+    const rt_material* mesh_materials, uint32_t n_meshes, const rt_image* images, uint32_t n_images,
+    const int32_t env_faces[6], const rt_sphere* spheres, uint32_t n_spheres, uint64_t* generation)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_scene_upload: ctx is NULL");
+    if (!nodes || n_nodes == 0)
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: a BVH needs at least its root node");
+    if ((n_prims && !prims) || (n_meshes && !mesh_materials) || (n_images && !images) || (n_spheres && !spheres))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: NULL array with non-zero count");
+    if (n_prims > kLeafOffsetMask)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: %u primitives exceed the %u supported", n_prims, kLeafOffsetMask);
+    for (uint32_t i = 0; i < n_prims; i++)
+        if (prims[i].meshID >= n_meshes)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: primitive %u names mesh %u of %u", i, prims[i].meshID, n_meshes);
+    for (uint32_t i = 0; i < n_meshes; i++)
+        if (mesh_materials[i].kdTexture >= (int32_t)n_images)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: material %u names image %d of %u", i, mesh_materials[i].kdTexture, n_images);
+    for (uint32_t i = 0; i < n_images; i++)
+        if (!images[i].pixels || images[i].width <= 0 || images[i].height <= 0)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: image %u is empty", i);
+    for (int i = 0; i < 6; i++)
+        if (env_faces && env_faces[i] >= (int32_t)n_images)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: environment face %d names image %d of %u", i, env_faces[i], n_images);
+
+    // Walk the tree from the root: every child index in range, every node
+    // reached once, leaves inside the primitive array and small enough for the
+    // packed child reference.
+    std::vector<int32_t> pairIndex(n_nodes, -1);
+    std::vector<uint8_t> seen(n_nodes, 0);
+    std::vector<uint32_t> innerOrder; // inner nodes in depth-first pre-order
+    struct Item {
+        uint32_t node, level;
+    };
+    std::vector<Item> work { { 0u, 1u } };
+    uint32_t maxLevel = 1;
+    while (!work.empty()) {
+        const Item it = work.back();
+        work.pop_back();
+        if (it.node >= n_nodes)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: child index %u out of %u nodes", it.node, n_nodes);
+        if (seen[it.node])
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: node %u is reachable twice (not a tree)", it.node);
+        seen[it.node] = 1;
+        maxLevel = std::max(maxLevel, it.level);
+        const rt_node& nd = nodes[it.node];
+        if (nd.data[0] & RT_LEAF_BIT) {
+            const uint32_t off = nd.data[0] & ~RT_LEAF_BIT, cnt = nd.data[1];
+            if (cnt > (uint32_t)kMaxLeafCount)
+                return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: leaf %u holds %u primitives (max %d)", it.node, cnt, kMaxLeafCount);
+            if ((uint64_t)off + cnt > n_prims)
+                return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: leaf %u spans [%u, %u) of %u primitives", it.node, off, off + cnt, n_prims);
+        } else {
+            pairIndex[it.node] = static_cast<int32_t>(innerOrder.size());
+            innerOrder.push_back(it.node);
+            work.push_back({ nd.data[1], it.level + 1 });
+            work.push_back({ nd.data[0], it.level + 1 });
+        }
+    }
+    if (maxLevel > (uint32_t)kMaxStack)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: BVH has %u levels (max %d)", maxLevel, kMaxStack);
+
+    auto childRef = [&](uint32_t child) -> uint32_t {
+        const rt_node& c = nodes[child];
+        if (c.data[0] & RT_LEAF_BIT)
+            return kLeafFlag | (c.data[1] << 27) | (c.data[0] & ~RT_LEAF_BIT);
+        return static_cast<uint32_t>(pairIndex[child]);
+    };
+
+    std::vector<float4> pairs(innerOrder.size() * 4);
+    for (size_t k = 0; k < innerOrder.size(); k++) {
+        const rt_node& nd = nodes[innerOrder[k]];
+        const rt_node& l = nodes[nd.data[0]];
+        const rt_node& r = nodes[nd.data[1]];
+        float4* p = &pairs[4 * k];
+        p[0] = make_float4(l.lower[0], l.lower[1], l.lower[2], l.upper[0]);
+        p[1] = make_float4(l.upper[1], l.upper[2], r.lower[0], r.lower[1]);
+        p[2] = make_float4(r.lower[2], r.upper[0], r.upper[1], r.upper[2]);
+        const uint32_t rl = childRef(nd.data[0]), rr = childRef(nd.data[1]);
+        float fl, frr;
+        std::memcpy(&fl, &rl, 4);
+        std::memcpy(&frr, &rr, 4);
+        p[3] = make_float4(fl, frr, 0.0f, 0.0f);
+    }
+
+    std::vector<float4> tris(static_cast<size_t>(n_prims) * 6), attrs(static_cast<size_t>(n_prims) * 4);
+    for (uint32_t i = 0; i < n_prims; i++) {
+        const rt_primitive& q = prims[i];
+        const f3 v0 = { q.v0.position[0], q.v0.position[1], q.v0.position[2] };
+        const f3 v1 = { q.v1.position[0], q.v1.position[1], q.v1.position[2] };
+        const f3 v2 = { q.v2.position[0], q.v2.position[1], q.v2.position[2] };
+        const f3 c = cross(v1 - v0, v2 - v0);
+        const f3 n = c * (1.0f / sqrtf(dot(c, c)));
+        const float D = dot(v0, n);
+        const f3 E0 = cross(v2 - v0, n), E1 = cross(v0 - v1, n), E2 = cross(v1 - v2, n);
+        float4* t = &tris[6 * static_cast<size_t>(i)];
+        t[0] = make_float4(n.x, n.y, n.z, D);
+        t[1] = make_float4(E0.x, E0.y, E0.z, v0.x);
+        t[2] = make_float4(v0.y, v0.z, E1.x, E1.y);
+        t[3] = make_float4(E1.z, v1.x, v1.y, v1.z);
+        t[4] = make_float4(E2.x, E2.y, E2.z, v2.x);
+        t[5] = make_float4(v2.y, v2.z, 0.0f, 0.0f);
+        float4* a = &attrs[4 * static_cast<size_t>(i)];
+        float meshBits;
+        std::memcpy(&meshBits, &q.meshID, 4);
+        a[0] = make_float4(q.v0.normal[0], q.v0.normal[1], q.v0.normal[2], q.v1.normal[0]);
+        a[1] = make_float4(q.v1.normal[1], q.v1.normal[2], q.v2.normal[0], q.v2.normal[1]);
+        a[2] = make_float4(q.v2.normal[2], q.v0.texCoord[0], q.v0.texCoord[1], q.v1.texCoord[0]);
+        a[3] = make_float4(q.v1.texCoord[1], q.v2.texCoord[0], q.v2.texCoord[1], meshBits);
+    }
+
+    std::vector<DevMaterial> mats(n_meshes + n_spheres);
+    auto toDev = [](const rt_material& m) {
+        DevMaterial d {};
+        std::memcpy(d.kd, m.kd, 12);
+        std::memcpy(d.ks, m.ks, 12);
+        d.shininess = m.shininess;
+        d.transparency = m.transparency;
+        d.tex = m.kdTexture;
+        return d;
+    };
+    for (uint32_t i = 0; i < n_meshes; i++)
+        mats[i] = toDev(mesh_materials[i]);
+    std::vector<DevSphere> sph(n_spheres);
+    for (uint32_t i = 0; i < n_spheres; i++) {
+        if (spheres[i].material.kdTexture >= (int32_t)n_images)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: sphere %u names image %d of %u", i, spheres[i].material.kdTexture, n_images);
+        mats[n_meshes + i] = toDev(spheres[i].material);
+        std::memcpy(sph[i].center, spheres[i].center, 12);
+        sph[i].radius = spheres[i].radius;
+        sph[i].material = static_cast<int32_t>(n_meshes + i);
+    }
+    std::vector<DevTex> texs(n_images);
+    size_t texFloats = 0;
+    for (uint32_t i = 0; i < n_images; i++) {
+        texs[i].offset = static_cast<uint32_t>(texFloats);
+        texs[i].width = images[i].width;
+        texs[i].height = images[i].height;
+        texFloats += static_cast<size_t>(images[i].width) * images[i].height * 3;
+        if (texFloats > 0xffffffffull)
+            return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: textures exceed 2^32 floats");
+    }
+    std::vector<float> texels(texFloats);
+    for (uint32_t i = 0; i < n_images; i++)
+        std::memcpy(texels.data() + texs[i].offset, images[i].pixels, static_cast<size_t>(images[i].width) * images[i].height * 12);
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, uploadVec(&ctx->dPairs, pairs));
+    HIP_TRY(ctx, uploadVec(&ctx->dTris, tris));
+    HIP_TRY(ctx, uploadVec(&ctx->dAttrs, attrs));
+    HIP_TRY(ctx, uploadVec(&ctx->dMats, mats));
+    HIP_TRY(ctx, uploadVec(&ctx->dTexs, texs));
+    HIP_TRY(ctx, uploadVec(&ctx->dTexels, texels));
+    HIP_TRY(ctx, uploadVec(&ctx->dSpheres, sph));
+
+    DevScene& s = ctx->scene;
+    const int32_t keepLights = s.nLights;
+    const rt_light* keepLightPtr = s.lights;
+    s = DevScene {};
+    s.pairs = ctx->dPairs;
+    s.tris = ctx->dTris;
+    s.attrs = ctx->dAttrs;
+    s.mats = ctx->dMats;
+    s.texs = ctx->dTexs;
+    s.texels = ctx->dTexels;
+    s.spheres = ctx->dSpheres;
+    s.lights = keepLightPtr;
+    s.nLights = keepLights;
+    const rt_node& root = nodes[0];
+    s.rootRef = (root.data[0] & RT_LEAF_BIT) ? (kLeafFlag | (root.data[1] << 27) | (root.data[0] & ~RT_LEAF_BIT)) : 0u;
+    std::memcpy(s.rootLo, root.lower, 12);
+    std::memcpy(s.rootHi, root.upper, 12);
+    s.nPrims = n_prims;
+    s.nMeshes = static_cast<int32_t>(n_meshes);
+    s.nSpheres = static_cast<int32_t>(n_spheres);
+    s.nTex = static_cast<int32_t>(n_images);
+    for (int i = 0; i < 6; i++)
+        s.env[i] = env_faces ? env_faces[i] : -1;
+    ctx->numLevels = maxLevel;
+    ctx->haveScene = true;
+    ctx->generation++;
+    if (generation)
+        *generation = ctx->generation;
+    return RT_OK;
+}
+
+int rt_lights_set(rt_ctx* ctx, const rt_light* lights, uint32_t n)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_lights_set: ctx is NULL");
+    if (n && !lights)
+        return fail(ctx, RT_ERR_INVALID, "rt_lights_set: NULL array with non-zero count");
+    for (uint32_t i = 0; i < n; i++)
+        if (lights[i].type < 0 || lights[i].type > 2)
+            return fail(ctx, RT_ERR_INVALID, "rt_lights_set: light %u has type %d", i, lights[i].type);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n > ctx->lightCap || !ctx->dLights) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        if (ctx->dLights)
+            (void)hipFree(ctx->dLights);
+        ctx->lightCap = std::max<uint32_t>(n, 16);
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->dLights), ctx->lightCap * sizeof(rt_light)));
+    }
+    if (n)
+        HIP_TRY(ctx, hipMemcpy(ctx->dLights, lights, n * sizeof(rt_light), hipMemcpyHostToDevice));
+    ctx->scene.lights = ctx->dLights;
+    ctx->scene.nLights = static_cast<int32_t>(n);
+    return RT_OK;
+}
+
+int rt_features_set(rt_ctx* ctx, const rt_features* f)
+{
+    if (!ctx || !f)
+        return fail(ctx, RT_ERR_INVALID, "rt_features_set: NULL argument");
+    if (f->enableMotionBlur)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_features_set: motion blur (renderImageWithMotionBlur) is outside this path");
+    if (f->enableBloomEffect)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_features_set: bloom post-processing is outside this path");
+    if (f->shadingModel < 0 || f->shadingModel > 3)
+        return fail(ctx, RT_ERR_INVALID, "rt_features_set: shadingModel %d", f->shadingModel);
+    if (f->maxRayDepth < 0 || f->maxRayDepth > kMaxDepth)
+        return fail(ctx, RT_ERR_INVALID, "rt_features_set: maxRayDepth %d not in [0, %d]", f->maxRayDepth, kMaxDepth);
+    ctx->features = *f;
+    ctx->haveFeatures = true;
+    return RT_OK;
+}
+
+} // extern "C"
+
+// state after k draws of the LCG (src/sampler.h:18) = mul * seed + add
+static void lcgJump(uint64_t k, uint32_t& mul, uint32_t& add)
+{
+    mul = 1u;
+    add = 0u;
+    uint32_t stepMul = 747796405u, stepAdd = 2891336453u; // one draw; squared each round
+    while (k) {
+        if (k & 1) {
+            mul = mul * stepMul;
+            add = add * stepMul + stepAdd;
+        }
+        stepAdd = stepAdd * stepMul + stepAdd;
+        stepMul = stepMul * stepMul;
+        k >>= 1;
+    }
+}
+
+static DevFeat makeFeat(const rt_features& f)
+{
+    DevFeat d {};
+    d.shading = f.enableShading, d.reflections = f.enableReflections, d.shadows = f.enableShadows;
+    d.normalInterp = f.enableNormalInterp, d.texMapping = f.enableTextureMapping, d.accel = f.enableAccelStructure;
+    d.bilinear = f.enableBilinearTextureFiltering, d.transparency = f.enableTransparency, d.jitter = f.enableJitteredSampling;
+    d.shadingModel = f.shadingModel;
+    d.spp = f.numPixelSamples, d.shadowSamples = f.numShadowSamples;
+    d.dof = f.enableDepthOfField, d.envMap = f.enableEnvironmentMap, d.glossy = f.enableGlossyReflection;
+    d.glossySamples = f.numGlossySamples, d.glossyExponent = f.glossyExponent;
+    d.dofDistance = f.depthOfFieldDistance, d.dofDiameter = f.depthOfFieldCircleDiameter, d.dofSamples = f.numDepthOfFieldSamples;
+    d.maxDepth = f.maxRayDepth;
+    // src/render.cpp:58-70, :118: ray count and draws of the pixel-sample stretch
+    d.jitterN = static_cast<uint32_t>(std::round(std::sqrt(static_cast<float>(f.numPixelSamples))));
+    uint32_t drawsPerCamRay = 0;
+    if (f.numPixelSamples > 1) {
+        d.camRays = f.enableJitteredSampling ? d.jitterN * d.jitterN : f.numPixelSamples;
+        drawsPerCamRay = 2;
+    } else {
+        d.camRays = 1;
+    }
+    d.raysPerPixel = f.enableDepthOfField ? d.camRays * f.numDepthOfFieldSamples : d.camRays;
+    const uint64_t pixDraws = static_cast<uint64_t>(drawsPerCamRay) * d.camRays;
+    const uint64_t lensDraws = f.enableDepthOfField ? 2ull * d.camRays * f.numDepthOfFieldSamples : 0ull;
+    lcgJump(pixDraws, d.lensMul, d.lensAdd);
+    lcgJump(pixDraws + lensDraws, d.mainMul, d.mainAdd);
+    return d;
+}
+
+// Trackball accessors, framework/src/trackball.cpp:26-27, :71-74, :112-126,
+// with glm::quat(eulerAngles) (glm detail/type_quat.inl:208-217).
+static DevCamera makeCamera(const rt_camera& c)
+{
+    DevCamera d {};
+    d.halfH = std::tan(c.fovy / 2.0f);
+    d.halfW = c.aspect * d.halfH;
+    const float cx = std::cos(c.rotation[0] * 0.5f), cy = std::cos(c.rotation[1] * 0.5f), cz = std::cos(c.rotation[2] * 0.5f);
+    const float sx = std::sin(c.rotation[0] * 0.5f), sy = std::sin(c.rotation[1] * 0.5f), sz = std::sin(c.rotation[2] * 0.5f);
+    d.qw = cx * cy * cz + sx * sy * sz;
+    d.q.x = sx * cy * cz - cx * sy * sz;
+    d.q.y = cx * sy * cz + sx * cy * sz;
+    d.q.z = cx * cy * sz - sx * sy * cz;
+    d.pos = mk3(c.lookAt[0], c.lookAt[1], c.lookAt[2]) + quatRotate(d.qw, d.q, mk3(0.0f, 0.0f, -c.distance));
+    d.fwd = quatRotate(d.qw, d.q, mk3(0.0f, 0.0f, 1.0f));
+    d.up = quatRotate(d.qw, d.q, mk3(0.0f, 1.0f, 0.0f));
+    d.left = quatRotate(d.qw, d.q, mk3(1.0f, 0.0f, 0.0f));
+    return d;
+}
+
+static size_t shardTiles(int width, int height, int shard, int nShard)
+{
+    const size_t tiles = static_cast<size_t>((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
+    return (tiles > static_cast<size_t>(shard)) ? (tiles - shard + nShard - 1) / nShard : 0;
+}
+
+static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int height, int shard, int nShard, float* dOut,
+    size_t dOutFloats, hipStream_t stream, bool collect, bool timeIt)
+{
+    if (!ctx->haveScene)
+        return fail(ctx, RT_ERR_STATE, "render: no scene uploaded (rt_scene_upload)");
+    if (!ctx->haveFeatures)
+        return fail(ctx, RT_ERR_STATE, "render: no features set (rt_features_set)");
+    if (!camera || width <= 0 || height <= 0 || nShard <= 0 || shard < 0 || shard >= nShard)
+        return fail(ctx, RT_ERR_INVALID, "render: bad camera / size / shard (%dx%d, shard %d of %d)", width, height, shard, nShard);
+    if (static_cast<uint64_t>(width) * height > 0x3fffffffull)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "render: %dx%d exceeds the supported pixel count", width, height);
+    const size_t need = (nShard == 1) ? static_cast<size_t>(width) * height * 3 : shardTiles(width, height, shard, nShard) * 64 * 3;
+    if (!dOut || dOutFloats < need)
+        return fail(ctx, RT_ERR_INVALID, "render: output holds %zu floats, %zu needed", dOutFloats, need);
+
+    const DevFeat ft = makeFeat(ctx->features);
+    const DevCamera cam = makeCamera(*camera);
+    DevFrame fr {};
+    fr.width = width, fr.height = height;
+    fr.tilesX = (width + kTile - 1) / kTile, fr.tilesY = (height + kTile - 1) / kTile;
+    fr.shard = shard, fr.nShard = nShard;
+    fr.nWork = static_cast<uint32_t>(shardTiles(width, height, shard, nShard) * 64);
+    fr.packed = (nShard == 1) ? 0 : 1;
+
+    int variant = 0;
+    if (ctx->features.enableTransparency)
+        variant |= 1;
+    if (ctx->features.enableGlossyReflection && ctx->features.enableReflections)
+        variant |= 2;
+    if (ctx->features.enableDepthOfField)
+        variant |= 4;
+    if (collect)
+        variant |= 8;
+
+    const int blockThreads = 256;
+    const uint32_t stackEntries = std::max<uint32_t>(ctx->numLevels, 2);
+    const size_t lds = static_cast<size_t>(stackEntries) * blockThreads * 4;
+    int perCU = ctx->blocksPerCU;
+    if (perCU <= 0) {
+        HIP_TRY(ctx, renderOccupancy(variant, blockThreads, lds, &perCU));
+        perCU = std::max(1, std::min(perCU, 8));
+    }
+    const uint32_t wavesNeeded = fr.nWork / 64;
+    int blocks = std::min<int64_t>(static_cast<int64_t>(ctx->numCU) * perCU, (wavesNeeded + 3) / 4);
+    blocks = std::max(blocks, 1);
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, sizeof(DevCounters), stream));
+    if (timeIt)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    HIP_TRY(ctx, launchRender(variant, blocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, ctx->dCounters, dOut,
+                      ctx->minActive, ctx->logicRounds));
+    if (timeIt)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    return RT_OK;
+}
+
+static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
+{
+    DevCounters c;
+    HIP_TRY(ctx, hipMemcpy(&c, ctx->dCounters, sizeof c, hipMemcpyDeviceToHost));
+    if (stats) {
+        stats->rays = c.rays;
+        stats->inner_nodes = c.inner;
+        stats->tri_tests = c.tris;
+        stats->kernel_ms = 0.0f;
+        if (timed)
+            HIP_TRY(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->ev0, ctx->ev1));
+    }
+    return RT_OK;
+}
+
+extern "C" {
+
+size_t rt_shard_floats(int width, int height, int shard_index, int shard_count)
+{
+    if (width <= 0 || height <= 0 || shard_count <= 0 || shard_index < 0 || shard_index >= shard_count)
+        return 0;
+    if (shard_count == 1)
+        return static_cast<size_t>(width) * height * 3;
+    return shardTiles(width, height, shard_index, shard_count) * 64 * 3;
+}
+
+int rt_render(rt_ctx* ctx, const rt_camera* camera, int width, int height, float* out_rgb, rt_stats* stats)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_render: ctx is NULL");
+    if (!out_rgb)
+        return fail(ctx, RT_ERR_INVALID, "rt_render: out_rgb is NULL");
+    if (width <= 0 || height <= 0)
+        return fail(ctx, RT_ERR_INVALID, "rt_render: bad size %dx%d", width, height);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t floats = static_cast<size_t>(width) * height * 3;
+    if (floats > ctx->frameCap) {
+        if (ctx->dFrame)
+            (void)hipFree(ctx->dFrame);
+        ctx->dFrame = nullptr;
+        ctx->frameCap = 0;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->dFrame), floats * sizeof(float)));
+        ctx->frameCap = floats;
+    }
+    const int rc = renderCommon(ctx, camera, width, height, 0, 1, ctx->dFrame, floats, nullptr, false, true);
+    if (rc != RT_OK)
+        return rc;
+    HIP_TRY(ctx, hipMemcpy(out_rgb, ctx->dFrame, floats * sizeof(float), hipMemcpyDeviceToHost));
+    const int rs = readStats(ctx, stats, true);
+    if (rs != RT_OK)
+        return rs;
+    if (stats)
+        stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const rt_camera* camera, int width, int height, int shard_index, int shard_count,
+    void* d_out, size_t d_out_floats, void* stream, int collect_stats, rt_stats* stats)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_render_device: ctx is NULL");
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = renderCommon(ctx, camera, width, height, shard_index, shard_count, static_cast<float*>(d_out), d_out_floats,
+        static_cast<hipStream_t>(stream), collect_stats != 0, true);
+    if (rc != RT_OK)
+        return rc;
+    if (collect_stats) {
+        HIP_TRY(ctx, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        const int rs = readStats(ctx, stats, true);
+        if (rs != RT_OK)
+            return rs;
+        if (stats)
+            stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx* ctx, void* stream, rt_stats* stats)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_sync: ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        return readStats(ctx, stats, true);
+    }
+    return RT_OK;
+}
+
+int rt_deinterleave(rt_ctx* ctx, const void* d_packed, int width, int height, int shard_count, void* d_frame, void* stream)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_deinterleave: ctx is NULL");
+    if (!d_packed || !d_frame || width <= 0 || height <= 0 || shard_count <= 0)
+        return fail(ctx, RT_ERR_INVALID, "rt_deinterleave: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int tilesX = (width + kTile - 1) / kTile, tilesY = (height + kTile - 1) / kTile;
+    const size_t stride = shardTiles(width, height, 0, shard_count) * 64 * 3;
+    HIP_TRY(ctx, launchDeinterleave(static_cast<hipStream_t>(stream), static_cast<const float*>(d_packed),
+                      static_cast<float*>(d_frame), width, height, tilesX, tilesY, shard_count, stride));
+    return RT_OK;
+}
+
+int rt_intersect_batch(rt_ctx* ctx, rt_ray* rays, uint32_t n, rt_hit* hits)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_intersect_batch: ctx is NULL");
+    if (!ctx->haveScene)
+        return fail(ctx, RT_ERR_STATE, "rt_intersect_batch: no scene uploaded");
+    if (!ctx->haveFeatures)
+        return fail(ctx, RT_ERR_STATE, "rt_intersect_batch: no features set");
+    if (n == 0)
+        return RT_OK;
+    if (!rays || !hits)
+        return fail(ctx, RT_ERR_INVALID, "rt_intersect_batch: NULL array");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rt_ray* dRays = nullptr;
+    rt_hit* dHits = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dRays), n * sizeof(rt_ray)));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dHits), n * sizeof(rt_hit));
+    if (e == hipSuccess)
+        e = hipMemcpy(dRays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const DevFeat ft = makeFeat(ctx->features);
+        const int blockThreads = 256;
+        const size_t lds = static_cast<size_t>(std::max<uint32_t>(ctx->numLevels, 2)) * blockThreads * 4;
+        e = launchIntersect(blockThreads, lds, nullptr, ctx->scene, ft, dRays, dHits, n);
+    }
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        e = hipMemcpy(rays, dRays, n * sizeof(rt_ray), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(hits, dHits, n * sizeof(rt_hit), hipMemcpyDeviceToHost);
+    (void)hipFree(dRays);
+    if (dHits)
+        (void)hipFree(dHits);
+    if (e != hipSuccess)
+        return fail(ctx, RT_ERR_DEVICE, "rt_intersect_batch: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_eval_batch(rt_ctx* ctx, int kind, const float* in, uint32_t n, float* out, const void* aux)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_eval_batch: ctx is NULL");
+    static const int inW[] = { 12, 12, 9, 3, 3, 2, 3, 2, 2, 20 };
+    static const int outW[] = { 3, 3, 2, 3, 3, 6, 6, 0, 6, 3 };
+    if (kind < 0 || kind > RT_EVAL_SHADING)
+        return fail(ctx, RT_ERR_INVALID, "rt_eval_batch: unknown kind %d", kind);
+    if (n == 0)
+        return RT_OK;
+    if (!in || !out)
+        return fail(ctx, RT_ERR_INVALID, "rt_eval_batch: NULL array");
+    size_t inFloats = static_cast<size_t>(inW[kind]) * n, outFloats = static_cast<size_t>(outW[kind]) * n;
+    if (kind == RT_EVAL_SAMPLER) {
+        if (n != 1)
+            return fail(ctx, RT_ERR_INVALID, "rt_eval_batch: the sampler kind takes one record");
+        uint32_t cnt;
+        std::memcpy(&cnt, in + 1, 4);
+        if (cnt == 0 || cnt > (1u << 24))
+            return fail(ctx, RT_ERR_INVALID, "rt_eval_batch: sampler count %u", cnt);
+        outFloats = cnt;
+    }
+    if ((kind == RT_EVAL_TEX_NEAREST || kind == RT_EVAL_TEX_BILINEAR)) {
+        if (!ctx->haveScene)
+            return fail(ctx, RT_ERR_STATE, "rt_eval_batch: texture kinds need an uploaded scene");
+        for (uint32_t i = 0; i < n; i++)
+            if (!(in[3 * i] >= 0.0f && in[3 * i] < (float)ctx->scene.nTex))
+                return fail(ctx, RT_ERR_INVALID, "rt_eval_batch: record %u names image %g of %d", i, in[3 * i], ctx->scene.nTex);
+    }
+    if (kind == RT_EVAL_SEGMENT_LIGHT || kind == RT_EVAL_PARALLELOGRAM) {
+        const int w = inW[kind];
+        for (uint32_t i = 0; i < n; i++)
+            if (!(in[w * i] >= 0.0f && in[w * i] < (float)ctx->scene.nLights))
+                return fail(ctx, RT_ERR_INVALID, "rt_eval_batch: record %u names light %g of %d", i, in[w * i], ctx->scene.nLights);
+    }
+    DevCamera cam {};
+    if (kind == RT_EVAL_CAMERA_RAY) {
+        if (!aux)
+            return fail(ctx, RT_ERR_INVALID, "rt_eval_batch: the camera-ray kind needs aux = rt_camera*");
+        cam = makeCamera(*static_cast<const rt_camera*>(aux));
+    }
+    rt_features f = ctx->features;
+    if (!ctx->haveFeatures)
+        std::memset(&f, 0, sizeof f);
+    const DevFeat ft = makeFeat(f);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *dIn = nullptr, *dOut = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dIn), inFloats * sizeof(float)));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dOut), outFloats * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMemcpy(dIn, in, inFloats * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = launchEval(nullptr, ctx->scene, cam, ft, kind, dIn, dOut, n);
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        e = hipMemcpy(out, dOut, outFloats * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(dIn);
+    if (dOut)
+        (void)hipFree(dOut);
+    if (e != hipSuccess)
+        return fail(ctx, RT_ERR_DEVICE, "rt_eval_batch: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,444 @@
+// rt_device.hpp -- device-side data layout and per-ray / per-hit arithmetic
+// for gfx950.  Everything is FP32 VALU work (no dense contraction anywhere on
+// this path, so no MFMA).  The translation unit is built with
+// -ffp-contract=off: each float is rounded where the reference's scalar code
+// rounds it, and the only fused operations are the explicit ones in the
+// bounding-box test, whose result is made conservative instead of exact.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+
+namespace rt {
+
+// ----------------------------------------------------------------------------
+// glm-shaped vector helpers (operation order as in glm 0.9.9.9:
+// dot = (x+y)+z, cross per detail/func_geometric.inl:74-77,
+// normalize = v * (1/sqrt(dot)), vec/scalar = per-component division).
+// ----------------------------------------------------------------------------
+struct f3 {
+    float x, y, z;
+};
+struct f2 {
+    float x, y;
+};
+
+#define RT_HD __host__ __device__ __forceinline__
+
+RT_HD f3 mk3(float x, float y, float z) { return f3 { x, y, z }; }
+RT_HD f3 mk3(float s) { return f3 { s, s, s }; }
+RT_HD f3 operator+(f3 a, f3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+RT_HD f3 operator-(f3 a, f3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+RT_HD f3 operator-(f3 a) { return { -a.x, -a.y, -a.z }; }
+RT_HD f3 operator*(f3 a, f3 b) { return { a.x * b.x, a.y * b.y, a.z * b.z }; }
+RT_HD f3 operator*(f3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+RT_HD f3 operator*(float s, f3 a) { return { s * a.x, s * a.y, s * a.z }; }
+RT_HD f3 operator/(f3 a, float s) { return { a.x / s, a.y / s, a.z / s }; }
+RT_HD float dot(f3 a, f3 b)
+{
+    const float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+    return tx + ty + tz;
+}
+RT_HD f3 cross(f3 x, f3 y) { return { x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y }; }
+RT_HD float length(f3 v) { return sqrtf(dot(v, v)); }
+RT_HD f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+RT_HD float gmin(float x, float y) { return (y < x) ? y : x; } // glm::min, NaN behaviour included
+RT_HD float gmax(float x, float y) { return (x < y) ? y : x; } // glm::max
+RT_HD f3 clamp01(f3 v)
+{
+    return { gmin(gmax(v.x, 0.0f), 1.0f), gmin(gmax(v.y, 0.0f), 1.0f), gmin(gmax(v.z, 0.0f), 1.0f) };
+}
+RT_HD f3 mix3(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
+RT_HD bool allEpsEq(f3 a, f3 b, float eps)
+{
+    return fabsf(a.x - b.x) < eps && fabsf(a.y - b.y) < eps && fabsf(a.z - b.z) < eps;
+}
+RT_HD bool isZero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+
+// glm quat * vec3, detail/type_quat.inl:347-354
+RT_HD f3 quatRotate(float qw, f3 q, f3 v)
+{
+    const f3 uv = cross(q, v);
+    const f3 uuv = cross(q, uv);
+    return v + ((uv * qw) + uuv) * 2.0f;
+}
+
+// ----------------------------------------------------------------------------
+// Device-resident scene (HBM; the whole working set of the bundled scenes is a
+// few MB and lives in L2 / Infinity Cache after the first touches).
+//
+// pairs : one 64-B record per inner node = both children's boxes + child refs,
+//         so one inner-node visit is one 64-B fetch (4 x dwordx4 per lane):
+//           [0] loL.xyz hiL.x  [1] hiL.yz loR.xy  [2] loR.z hiR.xyz
+//           [3] refL refR 0 0   (as uint bits)
+//         child ref: inner -> index of the child's own pair record;
+//                    leaf  -> kLeafFlag | count << 27 | offset   (count <= 15)
+// tris  : one 96-B record per primitive (6 x dwordx4), holding the
+//         ray-independent part of the reference's plane + three edge tests:
+//           [0] n.xyz D        n = normalize(cross(v1-v0, v2-v0)), D = dot(v0, n)
+//           [1] E0.xyz v0.x    E0 = cross(v2-v0, n)
+//           [2] v0.yz E1.xy    E1 = cross(v0-v1, n)
+//           [3] E1.z v1.xyz
+//           [4] E2.xyz v2.x    E2 = cross(v1-v2, n)
+//           [5] v2.yz 0 0
+// attrs : one 64-B record per primitive, read once per accepted closest hit:
+//           [0] n0.xyz n1.x  [1] n1.yz n2.xy  [2] n2.z uv0.xy uv1.x
+//           [3] uv1.y uv2.xy meshID(bits)
+// ----------------------------------------------------------------------------
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kRefNone = 0x7fffffffu; // "no node": traversal finished
+constexpr uint32_t kLeafOffsetMask = (1u << 27) - 1u;
+constexpr int kMaxLeafCount = 15;
+constexpr int kMaxStack = 32;   // traversal stack entries per lane (LDS)
+constexpr int kMaxDepth = 7;    // deepest accepted maxRayDepth
+constexpr int kTile = 8;        // sharding / work-queue tile edge (8x8 = one wave)
+
+struct DevMaterial {
+    float kd[3];
+    float ks[3];
+    float shininess;
+    float transparency;
+    int32_t tex;
+    int32_t pad[3];
+};
+struct DevTex {
+    uint32_t offset; // in floats into the texel pool
+    int32_t width, height;
+    int32_t pad;
+};
+struct DevSphere {
+    float center[3];
+    float radius;
+    int32_t material; // slot
+    int32_t pad[3];
+};
+
+struct DevScene {
+    const float4* pairs;
+    const float4* tris;
+    const float4* attrs;
+    const DevMaterial* mats;
+    const DevTex* texs;
+    const float* texels;
+    const DevSphere* spheres;
+    const rt_light* lights;
+    uint32_t rootRef;
+    float rootLo[3], rootHi[3];
+    uint32_t nPrims;
+    int32_t nMeshes, nSpheres, nLights, nTex;
+    int32_t env[6];
+};
+
+struct DevCamera {
+    f3 pos, fwd, up, left;
+    f3 q;
+    float qw, halfW, halfH;
+};
+
+struct DevFeat {
+    int32_t shading, reflections, shadows, normalInterp, texMapping, accel, bilinear, transparency, jitter;
+    int32_t shadingModel;
+    uint32_t spp, shadowSamples;
+    int32_t dof, envMap, glossy;
+    uint32_t glossySamples;
+    float glossyExponent, dofDistance, dofDiameter;
+    uint32_t dofSamples;
+    int32_t maxDepth;
+    // derived per frame
+    uint32_t raysPerPixel, jitterN, camRays;
+    // LCG jump constants: state after k draws = mul*seed + add
+    uint32_t lensMul, lensAdd, mainMul, mainAdd;
+};
+
+struct DevFrame {
+    int32_t width, height, tilesX, tilesY;
+    int32_t shard, nShard;
+    uint32_t nWork; // local pixels = local tiles * 64
+    int32_t packed; // 0: write Screen order, 1: write shard-packed tiles
+};
+
+struct DevCounters {
+    unsigned long long rays, inner, tris;
+    uint32_t next; // work-queue head
+    uint32_t pad;
+};
+
+// ----------------------------------------------------------------------------
+// Sampler, src/sampler.h:13-46.  float(v)/4294967295.f: the divisor rounds to
+// 2^32 as a float, so the division is an exact scaling by 2^-32.
+// ----------------------------------------------------------------------------
+RT_HD float next1d(uint32_t& state)
+{
+    state = state * 747796405u + 2891336453u;
+    uint32_t v = state;
+    v ^= v >> ((v >> 28u) + 4u);
+    v *= 277803737u;
+    v ^= v >> 22u;
+    return static_cast<float>(v) * 2.3283064365386963e-10f;
+}
+
+// ----------------------------------------------------------------------------
+// Textures, src/texture.cpp:12-95.  The reference indexes without wrap or
+// clamp (out-of-range coordinates are undefined behaviour there); the final
+// texel index is clamped into the image here.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ f3 texelAt(const DevScene& sc, const DevTex& t, float index)
+{
+    const int last = t.width * t.height - 1;
+    int i = (index == index) ? (index >= 2147483520.0f ? last : (int)index) : 0;
+    i = i < 0 ? 0 : (i > last ? last : i);
+    const float* p = sc.texels + t.offset + 3u * (uint32_t)i;
+    return { p[0], p[1], p[2] };
+}
+__device__ __forceinline__ f3 sampleTextureNearest(const DevScene& sc, const DevTex& im, f2 uv)
+{
+    float i = uv.x * (float)im.width;
+    float j = (1.0f - uv.y) * (float)im.height;
+    if (i == (float)im.width)
+        i -= 1.0f;
+    if (j == (float)im.height)
+        j -= 1.0f;
+    const float index = floorf(j) * (float)im.width + floorf(i);
+    return texelAt(sc, im, index);
+}
+__device__ __forceinline__ f3 sampleTextureBilinear(const DevScene& sc, const DevTex& im, f2 uv)
+{
+    const float W = (float)im.width, H = (float)im.height;
+    float x = uv.x * W;
+    float y = (1.0f - uv.y) * H;
+    if ((x == 0 && y == 0) || (x == W && y == 0) || (x == 0 && y == H) || (x == W && y == H) || x <= 0.5f
+        || x >= W - 0.5f || y <= 0.5f || y >= H - 0.5f) {
+        if (x >= W)
+            x -= 1.0f;
+        if (y >= H)
+            y -= 1.0f;
+        return texelAt(sc, im, floorf(y) * W + floorf(x));
+    }
+    const float i1 = roundf(x) - 0.5f, i2 = roundf(x) + 0.5f;
+    const float j1 = roundf(y) - 0.5f, j2 = roundf(y) + 0.5f;
+    const float distI1 = fabsf(x - i1), distI2 = fabsf(i2 - x);
+    const f3 pix1 = texelAt(sc, im, floorf(j1) * W + floorf(i1));
+    const f3 pix2 = texelAt(sc, im, floorf(j1) * W + floorf(i2));
+    const f3 ix1 = distI2 * pix1 + distI1 * pix2;
+    const f3 pix3 = texelAt(sc, im, floorf(j2) * W + floorf(i1));
+    const f3 pix4 = texelAt(sc, im, floorf(j2) * W + floorf(i2));
+    const f3 ix2 = distI2 * pix3 + distI1 * pix4;
+    const float distJ1 = fabsf(y - j1), distJ2 = fabsf(j2 - y);
+    return distJ2 * ix1 + distJ1 * ix2;
+}
+__device__ __forceinline__ f3 sampleTexture(const DevScene& sc, int tex, f2 uv, bool bilinear)
+{
+    const DevTex t = sc.texs[tex];
+    return bilinear ? sampleTextureBilinear(sc, t, uv) : sampleTextureNearest(sc, t, uv);
+}
+
+// src/extra.cpp:378-459
+__device__ __forceinline__ f3 sampleEnvironmentMap(const DevScene& sc, const DevFeat& ft, f3 d)
+{
+    if (!ft.envMap)
+        return mk3(0.0f);
+    int chosen;
+    float u, v;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    if (ax >= ay && ax >= az) {
+        if (d.x > 0.0f) {
+            chosen = 0, u = d.z, v = d.y;
+        } else {
+            chosen = 1, u = -d.z, v = d.y;
+        }
+    } else if (ay >= az) {
+        if (d.y > 0.0f) {
+            chosen = 2, u = -d.x, v = -d.z;
+        } else {
+            chosen = 3, u = -d.x, v = d.z;
+        }
+    } else {
+        if (d.z > 0.0f) {
+            chosen = 4, u = -d.x, v = d.y;
+        } else {
+            chosen = 5, u = d.x, v = d.y;
+        }
+    }
+    const int tex = sc.env[chosen];
+    if (tex < 0)
+        return mk3(0.0f);
+    const float biggest = fmaxf(ax, fmaxf(ay, az));
+    u = (u / biggest + 1.0f) * 0.5f;
+    v = (v / biggest + 1.0f) * 0.5f;
+    return sampleTexture(sc, tex, { u, v }, ft.bilinear != 0);
+}
+
+// ----------------------------------------------------------------------------
+// Lights, src/light.cpp:26-74
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ f3 ld3(const float* p) { return { p[0], p[1], p[2] }; }
+
+__device__ __forceinline__ void sampleSegmentLight(float s, const rt_light& l, f3& pos, f3& col)
+{
+    pos = mix3(ld3(l.v + 0), ld3(l.v + 3), s);
+    col = mix3(ld3(l.v + 6), ld3(l.v + 9), s);
+}
+__device__ __forceinline__ void sampleParallelogramLight(f2 s, const rt_light& l, f3& pos, f3& col)
+{
+    const f3 v0 = ld3(l.v + 0), e1 = ld3(l.v + 3), e2 = ld3(l.v + 6);
+    pos = v0 + s.x * e1 + s.y * e2;
+    const float x = s.x, y = s.y;
+    const float a0 = length(cross(e1 * x, e2 * y));
+    const float a1 = length(cross(e1 * (1.0f - x), e2 * y));
+    const float a2 = length(cross(e1 * x, e2 * (1.0f - y)));
+    const float a3 = length(cross(e1 * (1.0f - x), e2 * (1.0f - y)));
+    const float total = a0 + a1 + a2 + a3;
+    const float bx = a0 / total, by = a1 / total, bz = a2 / total, bw = a3 / total;
+    col = bw * ld3(l.v + 9) + bz * ld3(l.v + 12) + by * ld3(l.v + 15) + bx * ld3(l.v + 18);
+}
+
+// ----------------------------------------------------------------------------
+// Shading, src/shading.cpp:29-213.  `kd` is sampleMaterialKd's result (texture
+// or material colour), which depends only on the hit and is fetched once.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ f3 linearGradientSample(float ti)
+{
+    const float ts[5] = { 0.1f, 0.22f, 0.5f, 0.78f, 0.9f };
+    const f3 cs[5] = {
+        { 215.f / 256.f, 210.f / 256.f, 203.f / 256.f },
+        { 250.f / 256.f, 250.f / 256.f, 240.f / 256.f },
+        { 145.f / 256.f, 170.f / 256.f, 175.f / 256.f },
+        { 255.f / 256.f, 250.f / 256.f, 205.f / 256.f },
+        { 170.f / 256.f, 170.f / 256.f, 170.f / 256.f },
+    };
+    if (ti <= ts[0])
+        return cs[0];
+    if (ti >= ts[4])
+        return cs[4];
+    f3 c1 = cs[0], c2 = cs[1];
+    float t1 = ts[0], t2 = ts[1];
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        if (ts[i] <= ti) {
+            c1 = cs[i], c2 = cs[i + 1];
+            t1 = ts[i], t2 = ts[i + 1];
+        }
+    }
+    const float t = (ti - t1) / (t2 - t1);
+    return mix3(c1, c2, t);
+}
+
+__device__ __forceinline__ f3 computeShading(const DevFeat& ft, f3 N, f3 kd, f3 ks, float shininess, f3 camDir,
+    f3 lightDir, f3 lightColor)
+{
+    if (!ft.shading)
+        return lightColor * kd;
+    if (ft.shadingModel == 3) {
+        const float cosTheta = dot(lightDir, N);
+        return lightColor * linearGradientSample(cosTheta);
+    }
+    // Lambertian term, src/shading.cpp:60-74
+    const float nl = dot(N, lightDir);
+    const f3 diffuse = (nl < 0.0f) ? mk3(0.0f) : lightColor * kd * nl;
+    if (ft.shadingModel == 0)
+        return diffuse;
+    float d;
+    if (ft.shadingModel == 1) {
+        const f3 reflected = lightDir - N * dot(N, lightDir) * 2.0f; // glm::reflect(l, n)
+        d = dot(reflected, camDir);
+    } else {
+        const f3 Hv = normalize(lightDir + camDir);
+        d = dot(N, Hv);
+    }
+    if (d < 0.0f)
+        return diffuse;
+    const f3 specular = lightColor * ks * powf(d, shininess);
+    return diffuse + specular;
+}
+
+// ----------------------------------------------------------------------------
+// Intersection arithmetic
+// ----------------------------------------------------------------------------
+struct TriRec {
+    f3 n;
+    float D;
+    f3 E0, v0, E1, v1, E2, v2;
+};
+
+__device__ __forceinline__ TriRec loadTri(const float4* __restrict__ tris, uint32_t i)
+{
+    const float4* p = tris + 6u * i;
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5];
+    TriRec r;
+    r.n = { a.x, a.y, a.z };
+    r.D = a.w;
+    r.E0 = { b.x, b.y, b.z };
+    r.v0 = { b.w, c.x, c.y };
+    r.E1 = { c.z, c.w, d.x };
+    r.v1 = { d.y, d.z, d.w };
+    r.E2 = { e.x, e.y, e.z };
+    r.v2 = { e.w, f.x, f.y };
+    return r;
+}
+
+// intersectRayWithTriangle (src/intersect.h:12; body only in the prebuilt
+// archive): plane hit t = (D - dot(o,n)) / dot(d,n) accepted iff 0 <= t <= tmax
+// (NaN rejects), then three inclusive edge tests dot(cross(edge, n), p - v) >= 0.
+// cross(edge, n), n and D do not depend on the ray and come from the record,
+// computed with the same operations in the same order.
+__device__ __forceinline__ bool triangleTest(const TriRec& r, f3 o, f3 d, float tmax, float& tOut)
+{
+    const float t = (r.D - dot(o, r.n)) / dot(d, r.n);
+    if (!(t >= 0.0f && t <= tmax))
+        return false;
+    const f3 p = o + d * t;
+    if (!(dot(r.E0, p - r.v0) >= 0.0f))
+        return false;
+    if (!(dot(r.E1, p - r.v1) >= 0.0f))
+        return false;
+    if (!(dot(r.E2, p - r.v2) >= 0.0f))
+        return false;
+    tOut = t;
+    return true;
+}
+
+// intersectRayWithShape(Sphere) (src/intersect.h:14)
+__device__ __forceinline__ bool sphereTest(const DevSphere& s, f3 o, f3 d, float tmax, float& tOut)
+{
+    const f3 oc = o - ld3(s.center);
+    const float B = 2.0f * dot(d, oc);
+    const float C = dot(oc, oc) - s.radius * s.radius;
+    const float disc = B * B - 4.0f * C;
+    const float sq = sqrtf(disc);
+    float t0 = (-B - sq) / 2.0f;
+    float t1 = (-B + sq) / 2.0f;
+    if (t0 < 0.0f)
+        t0 = 3.402823466e+38f;
+    if (t1 < 0.0f)
+        t1 = 3.402823466e+38f;
+    const float t = (t1 < t0) ? t1 : t0; // std::min(t0, t1)
+    if (!(t >= 0.0f && t < tmax))
+        return false;
+    tOut = t;
+    return true;
+}
+
+// Conservative slab test.  The reference's box routine divides per axis and
+// ignores an axis whose direction component is zero; the result there only
+// decides which nodes are visited and in which order, never the hit itself.
+// Here the slabs use one subtract and one multiply by 1/d per plane and the
+// interval is widened by a few ulp, so a box is never skipped that the exact
+// test would have entered.  A NaN slab (0 * inf) drops out of min/max, which
+// reproduces "ignore that axis".  Returns the entry distance clamped to 0.
+constexpr float kPadLo = 1.0f - 4.76837158e-7f; // 1 - 2^-21
+constexpr float kPadHi = 1.0f + 4.76837158e-7f; // 1 + 2^-21
+
+__device__ __forceinline__ bool boxTest(f3 lo, f3 hi, f3 o, f3 inv, float tmax, float& entry)
+{
+    const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    const float tIn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f)) * kPadLo;
+    const float tOut = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kPadHi;
+    entry = tIn;
+    return tIn <= tOut && tIn <= tmax;
+}
+
+} // namespace rt
