@@ -154,8 +154,11 @@ typedef struct {
     uint64_t rays;        /* BVHInterface::intersect invocations */
     uint64_t inner_nodes; /* sibling-pair records fetched (0 unless collected) */
     uint64_t tri_tests;   /* triangle records tested   (0 unless collected) */
-    float kernel_ms;      /* device time of the render kernel, HIP events */
+    float kernel_ms;      /* device time of the render kernel launches since the last
+                             stats read, summed; HIP events on the launch stream */
     float total_ms;       /* wall time of the call */
+    uint32_t launches;    /* render launches kernel_ms covers */
+    uint32_t reserved;
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -218,7 +221,9 @@ int rt_deinterleave(rt_ctx* ctx, const void* d_packed, int width, int height, in
                     void* d_frame, void* stream);
 
 /* Blocks until the work rt_render_device / rt_deinterleave enqueued on
- * `stream` has finished and returns the ray count of the last render. */
+ * `stream` has finished; stats (optional) receives the ray count of the last
+ * render and the summed device time of all render launches since the last
+ * stats read. */
 int rt_sync(rt_ctx* ctx, void* stream, rt_stats* stats);
 
 /* BVHInterface::intersect(state, ray, hitInfo), src/bvh_interface.h:61 ->

@@ -50,7 +50,9 @@ struct rt_ctx {
     DevCounters* dCounters = nullptr;
     float* dFrame = nullptr;
     size_t frameCap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // one HIP event pair per render launch since the last stats read
+    std::vector<hipEvent_t> evPool;
+    size_t evUsed = 0;
     DevScene scene {};
     bool haveScene = false;
     uint32_t numLevels = 1;
@@ -118,8 +120,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     rt_ctx* ctx = new rt_ctx;
     ctx->device = device_ordinal;
     ctx->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc(reinterpret_cast<void**>(&ctx->dCounters), sizeof(DevCounters)) != hipSuccess
-        || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->dCounters), sizeof(DevCounters)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, RT_ERR_DEVICE, "rt_ctx_create: device allocation failed");
     }
@@ -144,10 +145,8 @@ void rt_ctx_destroy(rt_ctx* ctx)
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
-    if (ctx->ev0)
-        (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1)
-        (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->evPool)
+        (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -632,12 +631,27 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     blocks = std::max(blocks, 1);
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, sizeof(DevCounters), stream));
-    if (timeIt)
-        HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    if (timeIt) {
+        if (ctx->evUsed + 2 > ctx->evPool.size()) {
+            if (ctx->evPool.size() >= 8192) { // unread launches pile up: fold them by waiting once
+                HIP_TRY(ctx, hipStreamSynchronize(stream));
+                ctx->evUsed = 0;
+            } else {
+                hipEvent_t a, b;
+                HIP_TRY(ctx, hipEventCreate(&a));
+                HIP_TRY(ctx, hipEventCreate(&b));
+                ctx->evPool.push_back(a);
+                ctx->evPool.push_back(b);
+            }
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed], stream));
+    }
     HIP_TRY(ctx, launchRender(variant, blocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, ctx->dCounters, dOut,
                       ctx->minActive, ctx->logicRounds));
-    if (timeIt)
-        HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    if (timeIt) {
+        HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed + 1], stream));
+        ctx->evUsed += 2;
+    }
     return RT_OK;
 }
 
@@ -650,9 +664,17 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
         stats->inner_nodes = c.inner;
         stats->tri_tests = c.tris;
         stats->kernel_ms = 0.0f;
-        if (timed)
-            HIP_TRY(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->ev0, ctx->ev1));
+        stats->launches = 0;
+        if (timed) {
+            for (size_t i = 0; i + 1 < ctx->evUsed; i += 2) {
+                float ms = 0.0f;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]));
+                stats->kernel_ms += ms;
+                stats->launches++;
+            }
+        }
     }
+    ctx->evUsed = 0;
     return RT_OK;
 }
 
