@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 sio = importlib.import_module("ray-tracer_amd.scene_io")
 capi = importlib.import_module("ray-tracer_amd.capi")
+sharding = importlib.import_module("ray-tracer_amd.sharding")
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X vector FP32, spec
@@ -143,7 +144,7 @@ def main():
             ctx.render_device(camera, width, height, frame.data_ptr(), frame.numel(), 0, 1, sptr)
         else:
             ctx.render_device(camera, width, height, packed.data_ptr(), packed.numel(), rank, world, sptr)
-            dist.gather(packed, [gathered[i] for i in range(world)] if rank == 0 else None, dst=0)
+            sharding.gather_packed(packed, rank, world, dist, gathered)
             if rank == 0:
                 ctx.deinterleave(gathered.data_ptr(), width, height, world, frame.data_ptr(), sptr)
 

@@ -1,0 +1,130 @@
+"""Host-side logic that needs no GPU: the C ABI loads and exports every
+declared symbol, the host BVH build equals the oracle's bit for bit, error
+behaviour, scene ingest, and the world-size-2 tile sharding over gloo."""
+import ctypes
+import importlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common
+import orc
+from common import sio
+
+capi = importlib.import_module("ray-tracer_amd.capi")
+sharding = importlib.import_module("ray-tracer_amd.sharding")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(common.ROOT, "include", "rt_amd.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|size_t|const char\*)\s+(rt_[a-z_]+)\s*\(", header, re.M))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+@pytest.mark.parametrize("name", ["SingleTriangle", "Cube", "CornellBox", "Monkey", "Teapot", "Dragon"])
+def test_host_bvh_build_equals_oracle(name):
+    prims = common.scene(name).primitives()
+    n1, p1, l1, f1 = capi.bvh_build(prims)
+    n2, p2, l2, f2 = orc.bvh_build(prims)
+    assert (l1, f1) == (l2, f2)
+    assert n1.tobytes() == n2.tobytes()
+    assert p1.tobytes() == p2.tobytes()
+
+
+def test_host_bvh_build_edge_cases():
+    nodes, prims, levels, leaves = capi.bvh_build(np.zeros(0, dtype=sio.PRIMITIVE))
+    assert len(nodes) == 2 and len(prims) == 0 and (levels, leaves) == (1, 1)
+    assert nodes[0]["data"].tolist() == [sio.LEAF_BIT, 0]
+    # degenerate: 9 identical triangles (all centroid keys tie)
+    p = np.zeros(9, dtype=sio.PRIMITIVE)
+    p["v1"]["position"] = (1, 0, 0)
+    p["v2"]["position"] = (0, 1, 0)
+    p["meshID"] = np.arange(9)
+    n1, p1, _, _ = capi.bvh_build(p)
+    n2, p2, _, _ = orc.bvh_build(p)
+    assert n1.tobytes() == n2.tobytes() and p1.tobytes() == p2.tobytes()
+    with pytest.raises(capi.RtError) as e:
+        capi.bvh_build(p, sah_binning=True)
+    assert e.value.code == -2
+
+
+def test_shard_floats_matches_python_layout():
+    for (w, h) in [(1920, 1080), (17, 9), (8, 8), (3840, 2160), (100, 1)]:
+        for world in (1, 2, 3, 4, 8):
+            for r in range(world):
+                assert capi.shard_floats(w, h, r, world) == sharding.shard_floats(w, h, r, world)
+    assert capi.shard_floats(0, 5, 0, 1) == 0 and capi.shard_floats(8, 8, 2, 2) == 0
+
+
+def test_pack_and_deinterleave_round_trip():
+    rng = np.random.default_rng(0)
+    for (w, h, world) in [(17, 9, 2), (64, 40, 3), (8, 8, 8), (33, 31, 4)]:
+        frame = rng.random((h, w, 3), dtype=np.float32)
+        packed = np.stack([sharding.pack_shard(frame, r, world) for r in range(world)])
+        assert np.array_equal(sharding.deinterleave(packed, w, h, world), frame)
+
+
+def test_obj_loader_submeshes_and_materials():
+    s = common.scene("CornellBox")
+    assert len(s.meshes) == 8 and sum(len(m.triangles) for m in s.meshes) == 32
+    c = common.scene("Cube")
+    assert len(c.meshes) == 6 and abs(float(c.meshes[0].material["transparency"]) - 0.452632) < 1e-6
+    t = common.scene("Teapot")
+    assert t.meshes[0].material["kdTexture"] == 0 and t.images[0].shape == (128, 128, 3)
+    assert np.allclose(t.meshes[0].material["ks"], 0.2) and float(t.meshes[0].material["shininess"]) == 10.0
+    pos = np.concatenate([m.vertices["position"] for m in t.meshes])
+    assert abs(np.linalg.norm(pos, axis=1).max() - 1.0) < 1e-5  # centre + unit scale
+    with pytest.raises(FileNotFoundError):
+        sio.load_mesh(os.path.join(common.DATA, "dragon.obj"))
+
+
+def test_dragon_standin_is_deterministic():
+    a, b = sio.dragon_standin(), sio.dragon_standin()
+    assert len(a.triangles) == 87130
+    assert a.vertices.tobytes() == b.vertices.tobytes() and a.triangles.tobytes() == b.triangles.tobytes()
+
+
+GLOO_WORKER = r"""
+import importlib, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path[:0] = [os.environ["RT_ROOT"], os.path.join(os.environ["RT_ROOT"], "oracle"), os.path.join(os.environ["RT_ROOT"], "tests")]
+import common, orc
+from common import sio
+sharding = importlib.import_module("ray-tracer_amd.sharding")
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+w, h = 52, 30
+scn = common.scene("CornellBox")
+f = common.features(enableShading=1, enableReflections=1, enableShadows=1, shadingModel=2)
+full, _ = orc.OracleScene(scn).render(f, sio.default_camera(w, h), w, h, threads=1)
+# each rank contributes only its own tiles of the frame
+packed = torch.from_numpy(sharding.pack_shard(full, rank, world))
+stride = sharding.shard_floats(w, h, 0, world)
+assert packed.numel() == stride
+gathered = torch.empty((world, stride), dtype=torch.float32) if rank == 0 else None
+sharding.gather_packed(packed, rank, world, dist, gathered)
+if rank == 0:
+    frame = sharding.deinterleave(gathered.numpy(), w, h, world)
+    assert np.array_equal(frame.view(np.uint32), full.view(np.uint32))
+    print("GLOO_OK")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_world_size_2_tile_gather_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER)
+    env = dict(os.environ, RT_ROOT=common.ROOT, OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29653", str(script)],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GLOO_OK" in out.stdout
