@@ -11,7 +11,7 @@ import numpy as np
 from . import scene_io as sio
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  # RT_AMD_LIB: A/B builds
 
 # every symbol include/rt_amd.h declares
 EXPORTS = [
@@ -53,6 +53,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with ray-tracer_amd/csrc/Makefile "
                                "(__graft_entry__.build()); the rendering path has no CPU fallback")
+        try:
+            # PyTorch ships its own HIP runtime; when both live in one process it has to be
+            # the first one loaded, otherwise torch finds no device afterwards.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         l.rt_last_error.restype = C.c_char_p
         l.rt_last_error.argtypes = [C.c_void_p]

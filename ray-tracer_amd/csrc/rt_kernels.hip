@@ -636,8 +636,12 @@ struct Shader {
     }
 };
 
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1
+#endif
+
 template <int V>
-__global__ __launch_bounds__(256) void renderKernel(const DevScene sc, const DevCamera cam, const DevFeat ft,
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene sc, const DevCamera cam, const DevFeat ft,
     const DevFrame fr, DevCounters* __restrict__ ctr, float* __restrict__ out, int minActive, int logicRounds)
 {
     extern __shared__ uint32_t stackMem[];
@@ -915,6 +919,9 @@ typedef void (*RenderFn)(const DevScene, const DevCamera, const DevFeat, const D
 
 static RenderFn renderVariant(int v)
 {
+#ifdef RT_FAST_BUILD // experiments: only the plain and the counting variant
+    return (v & 8) ? renderKernel<8> : renderKernel<0>;
+#endif
     switch (v) {
     case 0: return renderKernel<0>;
     case 1: return renderKernel<1>;
