@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -27,6 +28,32 @@ hipError_t launchDeinterleave(hipStream_t stream, const float* packed, float* fr
     int tilesY, int nShard, size_t shardStride);
 hipError_t launchEval(hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, int kind,
     const float* in, float* out, uint32_t n);
+
+// mirrors of the structs in rt_wavefront.hip
+struct NodeB {
+    uint32_t path;
+    int32_t depth;
+    int32_t child;
+    float cv[3];
+    uint32_t pad[2];
+};
+struct WfBuffers {
+    int32_t* pathHead;
+    uint8_t* pathCount;
+    uint32_t* pathBase;
+    float* pathEnv;
+    float4* nodeA;
+    NodeB* nodeB;
+    float* contrib;
+    uint32_t maxNodes;
+};
+struct WfParams {
+    uint32_t slotBegin, nSlots, R, slots, drawsPerHit, pixDraws, mainStart, chunk;
+};
+hipError_t wavefrontOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
+hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
+    hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
+    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive);
 } // namespace rt
 
 using namespace rt;
@@ -47,6 +74,7 @@ struct rt_ctx {
     DevSphere* dSpheres = nullptr;
     rt_light* dLights = nullptr;
     uint32_t lightCap = 0;
+    std::vector<rt_light> hostLights;
     DevCounters* dCounters = nullptr;
     float* dFrame = nullptr;
     size_t frameCap = 0;
@@ -63,6 +91,11 @@ struct rt_ctx {
     int minActive = 40;
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
+    int forcePerPixel = 0; // 1 = always use the per-pixel kernel
+    size_t workspaceCap = 64ull << 30; // bytes the wavefront path may hold
+    // wavefront workspace (grow-only)
+    void* wsPtr[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t wsBytes[7] = { 0, 0, 0, 0, 0, 0, 0 };
 };
 
 static int fail(rt_ctx* ctx, int code, const char* fmt, ...)
@@ -130,6 +163,10 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->logicRounds = std::max(1, atoi(s));
     if (const char* s = getenv("RT_AMD_BLOCKS_PER_CU"))
         ctx->blocksPerCU = atoi(s);
+    if (const char* s = getenv("RT_AMD_PER_PIXEL"))
+        ctx->forcePerPixel = atoi(s);
+    if (const char* s = getenv("RT_AMD_WORKSPACE_GB"))
+        ctx->workspaceCap = static_cast<size_t>(std::max(1, atoi(s))) << 30;
     *out = ctx;
     return RT_OK;
 }
@@ -143,6 +180,9 @@ void rt_ctx_destroy(rt_ctx* ctx)
     void* ptrs[] = { ctx->dPairs, ctx->dTris, ctx->dAttrs, ctx->dMats, ctx->dTexs, ctx->dTexels, ctx->dSpheres, ctx->dLights,
         ctx->dCounters, ctx->dFrame };
     for (void* p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    for (void* p : ctx->wsPtr)
         if (p)
             (void)hipFree(p);
     for (hipEvent_t e : ctx->evPool)
@@ -488,6 +528,7 @@ int rt_lights_set(rt_ctx* ctx, const rt_light* lights, uint32_t n)
     }
     if (n)
         HIP_TRY(ctx, hipMemcpy(ctx->dLights, lights, n * sizeof(rt_light), hipMemcpyHostToDevice));
+    ctx->hostLights.assign(lights, lights + n);
     ctx->scene.lights = ctx->dLights;
     ctx->scene.nLights = static_cast<int32_t>(n);
     return RT_OK;
@@ -608,27 +649,9 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     fr.nWork = static_cast<uint32_t>(shardTiles(width, height, shard, nShard) * 64);
     fr.packed = (nShard == 1) ? 0 : 1;
 
-    int variant = 0;
-    if (ctx->features.enableTransparency)
-        variant |= 1;
-    if (ctx->features.enableGlossyReflection && ctx->features.enableReflections)
-        variant |= 2;
-    if (ctx->features.enableDepthOfField)
-        variant |= 4;
-    if (collect)
-        variant |= 8;
-
     const int blockThreads = 256;
     const uint32_t stackEntries = std::max<uint32_t>(ctx->numLevels, 2);
     const size_t lds = static_cast<size_t>(stackEntries) * blockThreads * 4;
-    int perCU = ctx->blocksPerCU;
-    if (perCU <= 0) {
-        HIP_TRY(ctx, renderOccupancy(variant, blockThreads, lds, &perCU));
-        perCU = std::max(1, std::min(perCU, 8));
-    }
-    const uint32_t wavesNeeded = fr.nWork / 64;
-    int blocks = std::min<int64_t>(static_cast<int64_t>(ctx->numCU) * perCU, (wavesNeeded + 3) / 4);
-    blocks = std::max(blocks, 1);
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, sizeof(DevCounters), stream));
     if (timeIt) {
@@ -646,8 +669,100 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         }
         HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed], stream));
     }
-    HIP_TRY(ctx, launchRender(variant, blocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, ctx->dCounters, dOut,
-                      ctx->minActive, ctx->logicRounds));
+
+    const rt_features& F = ctx->features;
+    const bool perPixel = ctx->forcePerPixel || F.enableTransparency || (F.enableGlossyReflection && F.enableReflections);
+    if (perPixel) {
+        int variant = 0;
+        if (F.enableTransparency)
+            variant |= 1;
+        if (F.enableGlossyReflection && F.enableReflections)
+            variant |= 2;
+        if (F.enableDepthOfField)
+            variant |= 4;
+        if (collect)
+            variant |= 8;
+        int perCU = ctx->blocksPerCU;
+        if (perCU <= 0) {
+            HIP_TRY(ctx, renderOccupancy(variant, blockThreads, lds, &perCU));
+            perCU = std::max(1, std::min(perCU, 8));
+        }
+        const uint32_t wavesNeeded = fr.nWork / 64;
+        int blocks = std::min<int64_t>(static_cast<int64_t>(ctx->numCU) * perCU, (wavesNeeded + 3) / 4);
+        blocks = std::max(blocks, 1);
+        HIP_TRY(ctx, launchRender(variant, blocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, ctx->dCounters, dOut,
+                          ctx->minActive, ctx->logicRounds));
+    } else {
+        // ---- wavefront path: work items are camera rays and light samples
+        WfParams wp {};
+        wp.R = ft.raysPerPixel;
+        uint32_t slots = 0, drawsPerHit = 0;
+        {
+            for (const rt_light& l : ctx->hostLights) {
+                slots += (l.type == 0) ? 1u : F.numShadowSamples;
+                drawsPerHit += (l.type == 0) ? 0u : (l.type == 1 ? F.numShadowSamples : 2u * F.numShadowSamples);
+            }
+        }
+        wp.slots = slots;
+        wp.drawsPerHit = drawsPerHit;
+        wp.pixDraws = (F.numPixelSamples > 1 ? 2u : 0u) * ft.camRays;
+        wp.mainStart = wp.pixDraws + (F.enableDepthOfField ? 2u * ft.camRays * F.numDepthOfFieldSamples : 0u);
+        wp.chunk = 512;
+        if (wp.R == 0 || wp.R > 65535u)
+            return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
+        const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * (F.enableReflections ? F.maxRayDepth + 1 : 1);
+        const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + (F.enableEnvironmentMap ? 12 : 0))
+            + nodesPerPixel * (64 + sizeof(NodeB) + 12ull * std::max(1u, slots));
+        uint64_t batchSlots = ctx->workspaceCap / std::max<uint64_t>(1, bytesPerPixel);
+        batchSlots = std::min<uint64_t>(batchSlots, 0x7fffffffull / wp.R);                                       // path index in 31 bits
+        batchSlots = std::min<uint64_t>(batchSlots, 0xffffffffull / (nodesPerPixel * std::max(1u, slots)));      // item index in 32 bits
+        batchSlots = std::min<uint64_t>(batchSlots, fr.nWork) & ~63ull;
+        if (batchSlots == 0)
+            return fail(ctx, RT_ERR_UNSUPPORTED, "render: one tile of this frame needs more than the %zu-byte workspace", ctx->workspaceCap);
+        const uint64_t paths = batchSlots * wp.R, maxNodes = batchSlots * nodesPerPixel;
+        const size_t want[7] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
+            F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
+            static_cast<size_t>(maxNodes) * sizeof(NodeB), static_cast<size_t>(maxNodes) * 12 * std::max(1u, slots) };
+        for (int i = 0; i < 7; i++) {
+            if (ctx->wsBytes[i] < want[i]) {
+                HIP_TRY(ctx, hipStreamSynchronize(stream));
+                if (ctx->wsPtr[i])
+                    (void)hipFree(ctx->wsPtr[i]);
+                ctx->wsPtr[i] = nullptr;
+                ctx->wsBytes[i] = 0;
+                HIP_TRY(ctx, hipMalloc(&ctx->wsPtr[i], want[i]));
+                ctx->wsBytes[i] = want[i];
+            }
+        }
+        WfBuffers wb {};
+        wb.pathHead = static_cast<int32_t*>(ctx->wsPtr[0]);
+        wb.pathCount = static_cast<uint8_t*>(ctx->wsPtr[1]);
+        wb.pathBase = static_cast<uint32_t*>(ctx->wsPtr[2]);
+        wb.pathEnv = static_cast<float*>(ctx->wsPtr[3]);
+        wb.nodeA = static_cast<float4*>(ctx->wsPtr[4]);
+        wb.nodeB = static_cast<NodeB*>(ctx->wsPtr[5]);
+        wb.contrib = static_cast<float*>(ctx->wsPtr[6]);
+        wb.maxNodes = static_cast<uint32_t>(maxNodes);
+
+        const bool dof = F.enableDepthOfField != 0;
+        int pathPerCU = ctx->blocksPerCU, shadowPerCU = ctx->blocksPerCU;
+        if (pathPerCU <= 0) {
+            HIP_TRY(ctx, wavefrontOccupancy(dof, collect, blockThreads, lds, &pathPerCU, &shadowPerCU));
+            pathPerCU = std::max(1, std::min(pathPerCU, 8));
+            shadowPerCU = std::max(1, std::min(shadowPerCU, 8));
+        }
+        for (uint64_t begin = 0; begin < fr.nWork; begin += batchSlots) {
+            wp.slotBegin = static_cast<uint32_t>(begin);
+            wp.nSlots = static_cast<uint32_t>(std::min<uint64_t>(batchSlots, fr.nWork - begin));
+            if (begin != 0) // queue heads and the node allocator start over; the ray counters keep adding up
+                HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctx->dCounters) + offsetof(DevCounters, next), 0, 16, stream));
+            const uint64_t items = static_cast<uint64_t>(wp.nSlots) * wp.R;
+            const int pathBlocks = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->numCU) * pathPerCU, (items + 255) / 256)));
+            const int shadowBlocks = ctx->numCU * shadowPerCU;
+            HIP_TRY(ctx, launchWavefront(dof, collect, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
+                              wb, ctx->dCounters, dOut, ctx->minActive));
+        }
+    }
     if (timeIt) {
         HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed + 1], stream));
         ctx->evUsed += 2;

@@ -160,9 +160,9 @@ struct DevFrame {
 };
 
 struct DevCounters {
-    unsigned long long rays, inner, tris;
-    uint32_t next; // work-queue head
-    uint32_t pad;
+    unsigned long long rays, inner, tris; // accumulated over the frame
+    // work-queue heads and the node allocator; cleared before every batch
+    uint32_t next, nextShadow, nodes, pad;
 };
 
 // ----------------------------------------------------------------------------

@@ -1,4 +1,5 @@
-// rt_kernels.hip -- gfx950 kernels of the rendering hot path.
+// rt_kernels.hip -- the general render kernel, the batch intersect kernel and
+// the small helper kernels of the rendering hot path (gfx950).
 //
 // renderKernel: persistent 64-lane wavefronts.  Each lane owns one pixel at a
 // time and walks that pixel's whole ray tree in the reference's depth-first
@@ -6,18 +7,20 @@
 // samples, lens samples, light samples and glossy samples
 // (src/render.cpp:34-39), and how many draws a ray consumes depends on what it
 // hits.  The recursion of src/recursive.cpp:25-64 is unrolled into a per-lane
-// state machine with an explicit frame stack; every ray of every kind
-// (camera, reflection, pass-through, glossy, shadow) goes through ONE shared
-// while-while BVH traversal loop, so lanes that are in different places of
-// their ray trees still traverse together.  Lanes that finish a pixel pull the
-// next one from an atomic work queue of 8x8 tiles (wave-aggregated: one
-// atomic per 64 pixels), and the traversal loop is left early, by ballot
-// count, when too few lanes still have a ray in flight.
+// state machine with an explicit frame stack; every ray of every kind goes
+// through ONE shared while-while BVH traversal loop (rt_trace.hpp), so lanes
+// that are in different places of their ray trees still traverse together.
+// Lanes that finish a pixel pull the next one from an atomic work queue of 8x8
+// tiles (wave-aggregated: one atomic per 64 pixels).
 //
-// No MFMA: nothing here is a dense contraction.  The bound is FP32 VALU issue
-// under divergence plus L2 latency of dependent node fetches.
+// This kernel handles every feature combination (transparency, glossy
+// reflections included).  Frames without those two take the wavefront path of
+// rt_wavefront.hip instead, which spreads the rays of one pixel over many
+// lanes; both produce the same bits.
+//
+// No MFMA: nothing here is a dense contraction.
 
-#include "rt_device.hpp"
+#include "rt_trace.hpp"
 
 namespace rt {
 
@@ -25,18 +28,12 @@ enum Phase : int {
     PH_NEWPIXEL = 0, // wants a pixel from the queue
     PH_NEXTRAY,      // generate the pixel's next camera ray, or finish the pixel
     PH_TRACE,        // ray in flight in the shared traversal loop
-    PH_TRACED,       // traversal finished, result in tmax / hitPrim
     PH_LIGHT,        // direct-light loop over lights and light samples
     PH_RECURSE,      // direct light done: spawn reflection / glossy / pass-through
     PH_RETURN,       // a renderRay value is ready at `depth`
     PH_DEAD
 };
-enum RayKind : int { K_RADIANCE = 0, K_SHADOW_ANY = 1, K_SHADOW_CLOSEST = 2 };
 enum FrameStage : int { FR_REFLECT = 0, FR_GLOSSY = 1, FR_TRANSP = 2 };
-
-constexpr int kHitNone = -1;
-constexpr float kFltMax = 3.402823466e+38f;
-constexpr float kTwoPi = 6.28318530717958647692528676655900576f;
 
 constexpr int V_TRANSP = 1, V_GLOSSY = 2, V_DOF = 4, V_STATS = 8;
 
@@ -62,11 +59,11 @@ struct Lane {
     uint32_t sMain, sPix, sLens;
     uint32_t rayI;
     f3 Lpix;
-    f3 pof; // depth of field: point of focus of the current camera ray
+    f3 pof;
     // the hit being shaded
     int depth;
-    f3 P, rd, N, kd, mkd, ks;
-    float shin, tr;
+    HitCtx h;
+    f3 rd;
     // direct-light loop
     int li;
     uint32_t si;
@@ -76,150 +73,8 @@ struct Lane {
     // value handed back by PH_RETURN
     f3 value;
     // ray in flight
-    f3 o, d, inv;
-    float tmax, slen;
-    int hitPrim, kind;
-    uint32_t cur;
-    int sp;
-    uint32_t nrays, nInner, nTris;
-};
-
-__device__ __forceinline__ f3 rcp3(f3 d)
-{
-    return { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z) };
-}
-
-template <int V>
-struct Tracer {
-    const DevScene& sc;
-    const DevFeat& ft;
-    uint32_t* stk; // this lane's column of the LDS stack: entry e at stk[e * blockDim.x]
-    uint32_t stride;
-
-    __device__ __forceinline__ uint32_t pop(Lane& L) const
-    {
-        if (L.sp == 0)
-            return kRefNone;
-        L.sp--;
-        return stk[L.sp * stride];
-    }
-    __device__ __forceinline__ void push(Lane& L, uint32_t ref) const
-    {
-        stk[L.sp * stride] = ref;
-        L.sp++;
-    }
-
-    // One BVHInterface::intersect call begins (src/bvh.cpp:337-358).  The root
-    // box test of src/bvh.cpp:253-259 happens here, so a ray that misses the
-    // whole scene never enters the traversal loop.
-    __device__ __forceinline__ void launch(Lane& L, f3 o, f3 d, float tmax, int kind) const
-    {
-        L.o = o;
-        L.d = d;
-        L.inv = rcp3(d);
-        L.tmax = tmax;
-        L.slen = tmax;
-        L.kind = kind;
-        L.hitPrim = kHitNone;
-        L.sp = 0;
-        L.nrays++;
-        L.phase = PH_TRACE;
-        if (ft.accel) {
-            float e;
-            const f3 lo = { sc.rootLo[0], sc.rootLo[1], sc.rootLo[2] }, hi = { sc.rootHi[0], sc.rootHi[1], sc.rootHi[2] };
-            if (sc.nPrims != 0 && boxTest(lo, hi, o, L.inv, kFltMax, e)) {
-                L.cur = sc.rootRef;
-            } else {
-                L.cur = kRefNone;
-                L.phase = PH_TRACED;
-            }
-        } else {
-            // enableAccelStructure off: every primitive in order (src/bvh.cpp:344-351)
-            for (uint32_t i = 0; i < sc.nPrims; i++) {
-                const TriRec r = loadTri(sc.tris, i);
-                float t;
-                if (V & V_STATS)
-                    L.nTris++;
-                if (triangleTest(r, L.o, L.d, L.tmax, t)) {
-                    L.tmax = t;
-                    L.hitPrim = (int)i;
-                }
-            }
-            L.cur = kRefNone;
-            L.phase = PH_TRACED;
-        }
-    }
-
-    // Shared while-while traversal.  `minActive`: leave as soon as fewer lanes
-    // than this still have a ray in flight (0 = run every ray to completion).
-    __device__ __forceinline__ void run(Lane& L, int minActive) const
-    {
-        if (__ballot(L.phase == PH_TRACE) == 0ull)
-            return;
-        for (;;) {
-            if (L.phase == PH_TRACE)
-                step(L);
-            const int n = __popcll(__ballot(L.phase == PH_TRACE));
-            if (n == 0 || n < minActive)
-                break;
-        }
-    }
-
-    // Inner nodes until a leaf is reached, then that leaf.
-    __device__ __forceinline__ void step(Lane& L) const
-    {
-        {
-            // ---- inner nodes: one 64-B sibling-pair record per visit
-            while (!(L.cur & kLeafFlag) && L.cur != kRefNone) {
-                const float4* p = sc.pairs + 4u * L.cur;
-                const float4 a = p[0], b = p[1], c = p[2];
-                const uint2 refs = *reinterpret_cast<const uint2*>(p + 3);
-                if (V & V_STATS)
-                    L.nInner++;
-                float eL, eR;
-                const bool hL = boxTest({ a.x, a.y, a.z }, { a.w, b.x, b.y }, L.o, L.inv, L.tmax, eL);
-                const bool hR = boxTest({ b.z, b.w, c.x }, { c.y, c.z, c.w }, L.o, L.inv, L.tmax, eR);
-                if (hL && hR) {
-                    // nearer child first; on a tie the right child, as in src/bvh.cpp:301-307
-                    const bool leftFirst = eL < eR;
-                    push(L, leftFirst ? refs.y : refs.x);
-                    L.cur = leftFirst ? refs.x : refs.y;
-                } else if (hL) {
-                    L.cur = refs.x;
-                } else if (hR) {
-                    L.cur = refs.y;
-                } else {
-                    L.cur = pop(L);
-                }
-            }
-            // ---- leaf: every primitive of the leaf, in order (src/bvh.cpp:272-279)
-            if (L.cur != kRefNone) {
-                const uint32_t off = L.cur & kLeafOffsetMask;
-                const uint32_t cnt = (L.cur >> 27) & 15u;
-                bool done = false;
-                for (uint32_t i = 0; i < cnt; i++) {
-                    const TriRec r = loadTri(sc.tris, off + i);
-                    float t;
-                    if (V & V_STATS)
-                        L.nTris++;
-                    if (triangleTest(r, L.o, L.d, L.tmax, t)) {
-                        L.tmax = t;
-                        L.hitPrim = (int)(off + i);
-                        // Binary visibility only asks whether the closest hit lies more
-                        // than 1e-4 before the target (src/light.cpp:101-104); any hit
-                        // that does settles it, the closest one is at least as near.
-                        if (L.kind == K_SHADOW_ANY && fabsf(t - L.slen) > 0.0001f) {
-                            done = true;
-                            break;
-                        }
-                    }
-                }
-                L.cur = done ? kRefNone : pop(L);
-            }
-            if (L.cur == kRefNone)
-                L.phase = PH_TRACED;
-        }
-    }
+    RayState r;
+    uint32_t nrays;
 };
 
 template <int V>
@@ -228,22 +83,16 @@ struct Shader {
     const DevCamera& cam;
     const DevFeat& ft;
     const DevFrame& fr;
-    const Tracer<V>& tracer;
+    const Tracer<(V & V_STATS) != 0>& tracer;
     float* out;
-    Frame* frames;          // per-lane private arrays (scratch)
+    Frame* frames; // per-lane private arrays (scratch)
     GlossyFrame* gframes;
 
-    // Spheres are tested after the BVH, in order, against the current ray.t
-    // (src/bvh.cpp:354-355); a sphere hit is recorded as -2 - index.
-    __device__ __forceinline__ void spheres(Lane& L) const
+    __device__ __forceinline__ void launch(Lane& L, f3 o, f3 d, float tmax, int kind) const
     {
-        for (int s = 0; s < sc.nSpheres; s++) {
-            float t;
-            if (sphereTest(sc.spheres[s], L.o, L.d, L.tmax, t)) {
-                L.tmax = t;
-                L.hitPrim = -2 - s;
-            }
-        }
+        tracer.launch(L.r, o, d, tmax, kind);
+        L.nrays++;
+        L.phase = PH_TRACE;
     }
 
     __device__ __forceinline__ DevMaterial materialOfHit(int hitPrim) const
@@ -255,65 +104,15 @@ struct Shader {
         return sc.mats[sc.spheres[-2 - hitPrim].material];
     }
 
-    // updateHitInfo (src/bvh.cpp:18-48) for the accepted closest hit, followed by
-    // sampleMaterialKd (src/shading.cpp:13-24), which depends only on the hit.
-    __device__ __forceinline__ void shadeSetup(Lane& L) const
-    {
-        L.P = L.o + L.tmax * L.d;
-        L.rd = L.d;
-        DevMaterial m;
-        if (L.hitPrim >= 0) {
-            const uint32_t i = (uint32_t)L.hitPrim;
-            const TriRec r = loadTri(sc.tris, i);
-            const float4 a0 = sc.attrs[4u * i + 0], a1 = sc.attrs[4u * i + 1], a2 = sc.attrs[4u * i + 2], a3 = sc.attrs[4u * i + 3];
-            m = sc.mats[__float_as_uint(a3.w)];
-            f3 N = r.n;
-            f2 uv = { 0.0f, 0.0f };
-            if (ft.normalInterp || ft.texMapping) {
-                // computeBarycentricCoord, src/interpolate.cpp:13-24
-                const f3 n = cross(r.v1 - r.v0, r.v2 - r.v0);
-                const f3 na = cross(r.v2 - r.v1, L.P - r.v1);
-                const f3 nb = cross(r.v0 - r.v2, L.P - r.v2);
-                const float alpha = dot(n, na) / dot(n, n);
-                const float beta = dot(n, nb) / dot(n, n);
-                const float gamma = 1.0f - alpha - beta;
-                if (ft.normalInterp) // src/interpolate.cpp:34-40
-                    N = alpha * mk3(a0.x, a0.y, a0.z) + beta * mk3(a0.w, a1.x, a1.y) + gamma * mk3(a1.z, a1.w, a2.x);
-                if (ft.texMapping) { // src/interpolate.cpp:50-55
-                    uv.x = a2.y * alpha + a2.w * beta + a3.y * gamma;
-                    uv.y = a2.z * alpha + a3.x * beta + a3.z * gamma;
-                }
-            }
-            if (dot(L.d, r.n) > 0.0f)
-                N = -N;
-            L.N = N;
-            L.kd = (ft.texMapping && m.tex >= 0) ? sampleTexture(sc, m.tex, uv, ft.bilinear != 0) : ld3(m.kd);
-        } else {
-            const DevSphere s = sc.spheres[-2 - L.hitPrim];
-            m = sc.mats[s.material];
-            L.N = normalize(L.P - ld3(s.center));
-            L.kd = ld3(m.kd);
-        }
-        L.mkd = ld3(m.kd);
-        L.ks = ld3(m.ks);
-        L.shin = m.shininess;
-        L.tr = m.transparency;
-        L.li = 0;
-        L.si = 0;
-        L.Lo = mk3(0.0f);
-        L.acc = mk3(0.0f);
-        L.phase = PH_LIGHT;
-    }
-
     // computeContributionPointLight after visibility is known (src/light.cpp:171-186),
     // then the per-light bookkeeping of src/light.cpp:205-219 / :239-253 / :283-298.
     __device__ __forceinline__ void addSample(Lane& L, f3 visible, f3 l, int type) const
     {
         if (!isZero(visible)) {
-            f3 N = L.N;
-            if (ft.transparency && L.tr < 1.0f && dot(L.N, l) < 0.0f)
-                N = -L.N;
-            L.acc = L.acc + computeShading(ft, N, L.kd, L.ks, L.shin, -L.rd, l, visible);
+            f3 N = L.h.N;
+            if (ft.transparency && L.h.tr < 1.0f && dot(L.h.N, l) < 0.0f)
+                N = -L.h.N;
+            L.acc = L.acc + computeShading(ft, N, L.h.kd, L.h.ks, L.h.shin, -L.rd, l, visible);
         } else {
             L.acc = L.acc + mk3(0.0f);
         }
@@ -355,39 +154,39 @@ struct Shader {
             sampleParallelogramLight({ sx, sy }, light, pos, col);
         }
         if (!ft.shadows) { // src/light.cpp:270-272
-            addSample(L, col, normalize(pos - L.P), type);
+            addSample(L, col, normalize(pos - L.h.P), type);
             return;
         }
         // shadow ray from the light to the hit point, src/light.cpp:94-97 / :128-131
         L.lcol = col;
-        const f3 toHit = L.P - pos;
+        const f3 toHit = L.h.P - pos;
         const f3 sd = normalize(toHit);
         const float len = length(toHit);
         if ((V & V_TRANSP) && ft.transparency) {
             L.tprod = 1.0f;
-            L.curKd = L.mkd;
-            tracer.launch(L, pos, sd, len, K_SHADOW_CLOSEST);
+            L.curKd = L.h.mkd;
+            launch(L, pos, sd, len, K_SHADOW_CLOSEST);
         } else {
-            tracer.launch(L, pos, sd, len, K_SHADOW_ANY);
+            launch(L, pos, sd, len, K_SHADOW_ANY);
         }
     }
 
     __device__ __forceinline__ void shadowDone(Lane& L) const
     {
         const int type = sc.lights[L.li].type;
-        const f3 l = -L.d; // normalize(light - p) == -normalize(p - light), exactly
-        if (L.kind == K_SHADOW_ANY) {
+        const f3 l = -L.r.d; // normalize(light - p) == -normalize(p - light), exactly
+        if (L.r.kind == K_SHADOW_ANY) {
             // src/light.cpp:101-107
-            const bool visible = (L.hitPrim == kHitNone) ? true : (fabsf(L.tmax - L.slen) <= 0.0001f);
+            const bool visible = (L.r.hitPrim == kHitNone) ? true : (fabsf(L.r.tmax - L.r.slen) <= 0.0001f);
             addSample(L, visible ? L.lcol : mk3(0.0f), l, type);
             return;
         }
         // src/light.cpp:138-150
         if (V & V_TRANSP) {
-            const f3 hp = L.o + L.tmax * L.d;
+            const f3 hp = L.r.o + L.r.tmax * L.r.d;
             bool again = false;
-            if (L.hitPrim != kHitNone && !allEpsEq(hp, L.P, 0.0001f)) {
-                const DevMaterial hm = materialOfHit(L.hitPrim);
+            if (L.r.hitPrim != kHitNone && !allEpsEq(hp, L.h.P, 0.0001f)) {
+                const DevMaterial hm = materialOfHit(L.r.hitPrim);
                 if (hm.transparency != 1.0f) {
                     L.curKd = ld3(hm.kd);
                     L.tprod *= hm.transparency;
@@ -395,23 +194,14 @@ struct Shader {
                 }
             }
             if (again) {
-                tracer.launch(L, hp + L.d * 1.0e-5f, L.d, kFltMax, K_SHADOW_CLOSEST); // src/recursive.cpp:98-111
+                launch(L, hp + L.r.d * 1.0e-5f, L.r.d, kFltMax, K_SHADOW_CLOSEST); // src/recursive.cpp:98-111
                 return;
             }
             f3 visible = mk3(0.0f);
-            if (allEpsEq(hp, L.P, 0.0001f))
+            if (allEpsEq(hp, L.h.P, 0.0001f))
                 visible = L.lcol * L.curKd * L.tprod;
-            // l must be the direction to the light sample; pass-through rays keep the direction
             addSample(L, visible, l, type);
         }
-    }
-
-    // src/recursive.cpp:72-89
-    __device__ __forceinline__ void reflectionRay(const f3& P, const f3& rd, const f3& N, f3& o, f3& d) const
-    {
-        const f3 nd = normalize(rd);
-        d = normalize(nd - 2.0f * dot(nd, N) * N);
-        o = P + N * 1.0e-5f;
     }
 
     __device__ __forceinline__ void glossyLaunch(Lane& L, int fi) const
@@ -427,7 +217,7 @@ struct Shader {
             const f3 sV = g.v * r * sinf(theta);
             const f3 dir = normalize(g.R + sU + sV);
             L.depth = fi + 1;
-            tracer.launch(L, f.P + dir * 1.0e-5f, dir, kFltMax, K_RADIANCE);
+            launch(L, f.P + dir * 1.0e-5f, dir, kFltMax, K_RADIANCE);
         }
     }
 
@@ -439,7 +229,7 @@ struct Shader {
             f.Lo = Lo;
             f.stage = FR_TRANSP;
             L.depth = fi + 1;
-            tracer.launch(L, f.P + f.rd * 1.0e-5f, f.rd, kFltMax, K_RADIANCE); // src/recursive.cpp:98-111
+            launch(L, f.P + f.rd * 1.0e-5f, f.rd, kFltMax, K_RADIANCE); // src/recursive.cpp:98-111
             return;
         }
         L.value = Lo;
@@ -452,43 +242,43 @@ struct Shader {
     {
         const int fi = L.depth;
         if (fi < ft.maxDepth) {
-            const bool reflective = !(L.ks.x == 0.0f && L.ks.y == 0.0f && L.ks.z == 0.0f);
-            const bool transparent = L.tr != 1.0f;
+            const bool reflective = !(L.h.ks.x == 0.0f && L.h.ks.y == 0.0f && L.h.ks.z == 0.0f);
+            const bool transparent = L.h.tr != 1.0f;
             const bool wantRefl = ft.reflections && reflective;
             const bool wantTr = (V & V_TRANSP) && ft.transparency && transparent;
             if (wantRefl || wantTr) {
                 Frame& f = frames[fi];
                 f.Lo = L.Lo;
-                f.ks = L.ks;
-                f.P = L.P;
+                f.ks = L.h.ks;
+                f.P = L.h.P;
                 f.rd = L.rd;
-                f.tr = L.tr;
+                f.tr = L.h.tr;
                 if (wantRefl && !ft.glossy) {
                     f.stage = FR_REFLECT;
                     f3 o, d;
-                    reflectionRay(L.P, L.rd, L.N, o, d);
+                    reflectionRay(L.h.P, L.rd, L.h.N, o, d);
                     L.depth = fi + 1;
-                    tracer.launch(L, o, d, kFltMax, K_RADIANCE);
+                    launch(L, o, d, kFltMax, K_RADIANCE);
                     return;
                 }
                 if ((V & V_GLOSSY) && wantRefl && ft.glossy) { // src/extra.cpp:329-368
                     f.stage = FR_GLOSSY;
                     GlossyFrame& g = gframes[fi];
                     f3 o;
-                    reflectionRay(L.P, L.rd, L.N, o, g.R);
+                    reflectionRay(L.h.P, L.rd, L.h.N, o, g.R);
                     f3 arbitrary = { 1.0f, 0.0f, 0.0f };
                     if (length(arbitrary - g.R) < 0.01f)
                         arbitrary = { 0.0f, 1.0f, 0.0f };
                     g.u = normalize(cross(arbitrary, g.R));
                     g.v = normalize(cross(g.R, g.u));
-                    g.radius = ft.glossyExponent * L.shin / 64.0f;
+                    g.radius = ft.glossyExponent * L.h.shin / 64.0f;
                     g.acc = mk3(0.0f);
                     g.i = 0;
                     if ((int)ft.glossySamples > 0) {
                         glossyLaunch(L, fi);
                         return;
                     }
-                    const f3 Lo = L.Lo + (g.acc / (float)(int)ft.glossySamples) * L.ks;
+                    const f3 Lo = L.Lo + (g.acc / (float)(int)ft.glossySamples) * L.h.ks;
                     afterReflection(L, fi, Lo);
                     return;
                 }
@@ -528,17 +318,6 @@ struct Shader {
         }
     }
 
-    // Trackball::generateRay, framework/src/trackball.cpp:101-110
-    __device__ __forceinline__ f3 cameraDir(float ndcX, float ndcY) const
-    {
-        const f3 c = normalize(mk3(-ndcX * cam.halfW, ndcY * cam.halfH, 1.0f));
-        return quatRotate(cam.qw, cam.q, c);
-    }
-
-    // generatePixelRays* (src/render.cpp:56-131) and the lens fan-out of
-    // src/extra.cpp:48-81, one ray at a time: the pixel-sample draws, the lens
-    // draws and the draws of the ray trees are three consecutive stretches of
-    // the pixel's stream, so each gets its own cursor.
     __device__ __forceinline__ void nextRay(Lane& L) const
     {
         if (L.rayI >= ft.raysPerPixel) {
@@ -550,55 +329,14 @@ struct Shader {
             L.phase = PH_NEWPIXEL;
             return;
         }
-        const uint32_t dofN = ((V & V_DOF) && ft.dof) ? ft.dofSamples : 1u;
-        const uint32_t c = L.rayI / dofN;
-        f3 dir;
-        if (!((V & V_DOF) && ft.dof) || (L.rayI % dofN) == 0) {
-            float ndcX, ndcY;
-            const float W = (float)fr.width, H = (float)fr.height;
-            if (ft.spp > 1) {
-                if (ft.jitter) {
-                    const int p = (int)(c / ft.jitterN), q = (int)(c % ft.jitterN);
-                    const float a = next1d(L.sPix);
-                    const float b = next1d(L.sPix);
-                    const float jx = (float)L.px + ((float)p + a) / (float)ft.jitterN;
-                    const float jy = (float)L.py + ((float)q + b) / (float)ft.jitterN;
-                    ndcX = jx / W * 2.0f - 1.0f;
-                    ndcY = jy / H * 2.0f - 1.0f;
-                } else {
-                    const float a = next1d(L.sPix);
-                    const float b = next1d(L.sPix);
-                    ndcX = ((float)L.px + a) / W * 2.0f - 1.0f;
-                    ndcY = ((float)L.py + b) / H * 2.0f - 1.0f;
-                }
-            } else {
-                ndcX = ((float)L.px + 0.5f) / W * 2.0f - 1.0f;
-                ndcY = ((float)L.py + 0.5f) / H * 2.0f - 1.0f;
-            }
-            dir = cameraDir(ndcX, ndcY);
-            if ((V & V_DOF) && ft.dof) { // getPointOfFocus, src/extra.cpp:15-23
-                const float cosAngle = dot(dir, cam.fwd);
-                const float curDistance = ft.dofDistance / cosAngle;
-                L.pof = cam.pos + curDistance * dir;
-            }
-        }
+        f3 o, d;
+        cameraRay<(V & V_DOF) != 0>(cam, ft, fr, L.px, L.py, L.rayI, L.sPix, L.sLens, L.pof, o, d);
         L.depth = 0;
-        if ((V & V_DOF) && ft.dof) { // src/extra.cpp:27-44, :70-76
-            const float r0 = next1d(L.sLens);
-            const float r1 = next1d(L.sLens);
-            const float angle = r0 * kTwoPi;
-            const float dist = sqrtf(r1) * (ft.dofDiameter * 0.5f);
-            const float ox = cosf(angle) * dist;
-            const float oy = sinf(angle) * dist;
-            const f3 o = cam.pos + ox * cam.up + oy * cam.left;
-            tracer.launch(L, o, normalize(L.pof - o), kFltMax, K_RADIANCE);
-        } else {
-            tracer.launch(L, cam.pos, dir, kFltMax, K_RADIANCE);
-        }
+        launch(L, o, d, kFltMax, K_RADIANCE);
     }
 
-    // Run this lane's state machine until it has a ray in flight, wants a new
-    // pixel, or is dead.
+    // Run this lane's state machine until it has a ray in the traversal loop,
+    // wants a new pixel, or is dead.
     __device__ __forceinline__ void advance(Lane& L) const
     {
         for (;;) {
@@ -606,15 +344,23 @@ struct Shader {
             case PH_NEXTRAY:
                 nextRay(L);
                 break;
-            case PH_TRACED:
+            case PH_TRACE:
+                if (L.r.active)
+                    return;
                 if (sc.nSpheres)
-                    spheres(L);
-                if (L.kind == K_RADIANCE) {
-                    if (L.hitPrim == kHitNone) { // src/recursive.cpp:29-32
-                        L.value = sampleEnvironmentMap(sc, ft, L.d);
+                    tracer.spheres(L.r);
+                if (L.r.kind == K_RADIANCE) {
+                    if (L.r.hitPrim == kHitNone) { // src/recursive.cpp:29-32
+                        L.value = sampleEnvironmentMap(sc, ft, L.r.d);
                         L.phase = PH_RETURN;
                     } else {
-                        shadeSetup(L);
+                        L.h = shadeHit(sc, ft, L.r);
+                        L.rd = L.r.d;
+                        L.li = 0;
+                        L.si = 0;
+                        L.Lo = mk3(0.0f);
+                        L.acc = mk3(0.0f);
+                        L.phase = PH_LIGHT;
                     }
                 } else {
                     shadowDone(L);
@@ -648,14 +394,16 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
     Frame frames[kMaxDepth + 1];
     GlossyFrame gframes[(V & V_GLOSSY) ? (kMaxDepth + 1) : 1];
 
-    const Tracer<V> tracer { sc, ft, stackMem + threadIdx.x, blockDim.x };
+    const Tracer<(V & V_STATS) != 0> tracer { sc, ft.accel, stackMem + threadIdx.x, blockDim.x };
     const Shader<V> shader { sc, cam, ft, fr, tracer, out, frames, gframes };
 
     Lane L;
     L.phase = PH_NEWPIXEL;
-    L.nrays = L.nInner = L.nTris = 0;
-    L.cur = kRefNone;
-    L.sp = 0;
+    L.nrays = 0;
+    L.r.nInner = L.r.nTris = 0;
+    L.r.cur = kRefNone;
+    L.r.sp = 0;
+    L.r.active = false;
     L.depth = 0;
 
     // Work queue: 64-pixel chunks (one 8x8 tile).  The first chunk of every
@@ -699,13 +447,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
                 const uint32_t nWant = __popcll(wm);
                 if (want && rank < avail) {
                     const uint32_t w = cursor + rank;
-                    const uint32_t tileLocal = w >> 6, within = w & 63u;
-                    const uint32_t tile = tileLocal * (uint32_t)fr.nShard + (uint32_t)fr.shard;
-                    const int tx = (int)(tile % (uint32_t)fr.tilesX), ty = (int)(tile / (uint32_t)fr.tilesX);
-                    L.px = tx * kTile + (int)(within & 7u);
-                    L.py = ty * kTile + (int)(within >> 3);
                     L.widx = w;
-                    if (L.px < fr.width && L.py < fr.height) {
+                    if (slotToPixel(fr, w, L.px, L.py)) {
                         const uint32_t seed = (uint32_t)(fr.height * L.px + L.py); // src/render.cpp:38
                         L.sPix = seed;
                         L.sLens = ft.lensMul * seed + ft.lensAdd;
@@ -714,8 +457,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
                         L.Lpix = mk3(0.0f);
                         L.phase = PH_NEXTRAY;
                     }
-                    // pixels of a partial edge tile that fall outside the frame are skipped:
-                    // the lane stays in PH_NEWPIXEL and takes part in the next hand-out
+                    // padding pixels of a partial edge tile are skipped: the lane stays in
+                    // PH_NEWPIXEL and takes part in the next hand-out
                 }
                 cursor += (nWant < avail) ? nWant : avail;
             }
@@ -729,11 +472,11 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
                 break;
             continue;
         }
-        tracer.run(L, exhausted ? 0 : minActive);
+        tracer.run(L.r, exhausted ? 0 : minActive);
     }
 
     // ---- counters: one atomic per wave
-    unsigned long long r = L.nrays, ni = L.nInner, nt = L.nTris;
+    unsigned long long r = L.nrays, ni = L.r.nInner, nt = L.r.nTris;
     for (int off = 32; off > 0; off >>= 1) {
         r += __shfl_down(r, off);
         if (V & V_STATS) {
@@ -757,13 +500,13 @@ __global__ __launch_bounds__(256) void intersectKernel(const DevScene sc, const 
     rt_hit* __restrict__ hits, uint32_t n)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<0> tracer { sc, ft, stackMem + threadIdx.x, blockDim.x };
+    const Tracer<false> tracer { sc, ft.accel, stackMem + threadIdx.x, blockDim.x };
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    Lane L;
-    L.phase = PH_DEAD;
-    L.nrays = 0;
+    RayState L;
     L.cur = kRefNone;
     L.sp = 0;
+    L.active = false;
+    L.nInner = L.nTris = 0;
     if (i < n) {
         const rt_ray r = rays[i];
         tracer.launch(L, ld3(r.origin), ld3(r.direction), r.t, K_RADIANCE);
@@ -771,13 +514,7 @@ __global__ __launch_bounds__(256) void intersectKernel(const DevScene sc, const 
     tracer.run(L, 0);
     if (i >= n)
         return;
-    for (int s = 0; s < sc.nSpheres; s++) {
-        float t;
-        if (sphereTest(sc.spheres[s], L.o, L.d, L.tmax, t)) {
-            L.tmax = t;
-            L.hitPrim = -2 - s;
-        }
-    }
+    tracer.spheres(L);
     rt_hit h;
     h.hit = (L.hitPrim != kHitNone) ? 1 : 0;
     h.t = L.tmax;

@@ -1,0 +1,303 @@
+// rt_trace.hpp -- the shared BVH traversal: every ray of every kernel (camera,
+// reflection, pass-through, glossy, shadow) runs through this one while-while
+// loop.  Per-lane state is a RayState; the short traversal stack lives in LDS,
+// one column per lane (entry e of lane t at stackBase[e * blockDim.x + t], so
+// the 64 lanes of a wave always hit 64 different banks).
+#pragma once
+
+#include "rt_device.hpp"
+
+namespace rt {
+
+enum RayKind : int { K_RADIANCE = 0, K_SHADOW_ANY = 1, K_SHADOW_CLOSEST = 2 };
+
+constexpr int kHitNone = -1;
+constexpr float kFltMax = 3.402823466e+38f;
+constexpr float kTwoPi = 6.28318530717958647692528676655900576f;
+
+struct RayState {
+    f3 o, d, inv;
+    float tmax, slen; // current closest t; the ray's original length (shadow rays)
+    int hitPrim;      // primitive index, kHitNone, or -2 - sphere index
+    int kind;
+    uint32_t cur;     // node reference being visited, kRefNone when finished
+    int sp;
+    bool active;      // still inside the traversal loop
+    uint32_t nInner, nTris;
+};
+
+__device__ __forceinline__ f3 rcp3(f3 d)
+{
+    return { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z) };
+}
+
+template <bool STATS>
+struct Tracer {
+    const DevScene& sc;
+    int accel;
+    uint32_t* stk; // this lane's column of the LDS stack
+    uint32_t stride;
+
+    __device__ __forceinline__ uint32_t pop(RayState& r) const
+    {
+        if (r.sp == 0)
+            return kRefNone;
+        r.sp--;
+        return stk[r.sp * stride];
+    }
+    __device__ __forceinline__ void push(RayState& r, uint32_t ref) const
+    {
+        stk[r.sp * stride] = ref;
+        r.sp++;
+    }
+
+    // One BVHInterface::intersect call begins (src/bvh.cpp:337-358).  The root
+    // box test of src/bvh.cpp:253-259 happens here, so a ray that misses the
+    // whole scene never enters the traversal loop.
+    __device__ __forceinline__ void launch(RayState& r, f3 o, f3 d, float tmax, int kind) const
+    {
+        r.o = o;
+        r.d = d;
+        r.inv = rcp3(d);
+        r.tmax = tmax;
+        r.slen = tmax;
+        r.kind = kind;
+        r.hitPrim = kHitNone;
+        r.sp = 0;
+        r.cur = kRefNone;
+        r.active = false;
+        if (accel) {
+            float e;
+            const f3 lo = { sc.rootLo[0], sc.rootLo[1], sc.rootLo[2] }, hi = { sc.rootHi[0], sc.rootHi[1], sc.rootHi[2] };
+            if (sc.nPrims != 0 && boxTest(lo, hi, o, r.inv, kFltMax, e)) {
+                r.cur = sc.rootRef;
+                r.active = true;
+            }
+        } else {
+            // enableAccelStructure off: every primitive in order (src/bvh.cpp:344-351)
+            for (uint32_t i = 0; i < sc.nPrims; i++) {
+                const TriRec tr = loadTri(sc.tris, i);
+                float t;
+                if (STATS)
+                    r.nTris++;
+                if (triangleTest(tr, r.o, r.d, r.tmax, t)) {
+                    r.tmax = t;
+                    r.hitPrim = (int)i;
+                }
+            }
+        }
+    }
+
+    // Shared while-while traversal.  `minActive`: leave as soon as fewer lanes
+    // than this still have a ray in flight (0 = run every ray to completion).
+    __device__ __forceinline__ void run(RayState& r, int minActive) const
+    {
+        if (__ballot(r.active) == 0ull)
+            return;
+        for (;;) {
+            if (r.active)
+                step(r);
+            const int n = __popcll(__ballot(r.active));
+            if (n == 0 || n < minActive)
+                break;
+        }
+    }
+
+    // Inner nodes until a leaf is reached, then that leaf.
+    __device__ __forceinline__ void step(RayState& r) const
+    {
+        // ---- inner nodes: one 64-B sibling-pair record per visit
+        while (!(r.cur & kLeafFlag) && r.cur != kRefNone) {
+            const float4* p = sc.pairs + 4u * r.cur;
+            const float4 a = p[0], b = p[1], c = p[2];
+            const uint2 refs = *reinterpret_cast<const uint2*>(p + 3);
+            if (STATS)
+                r.nInner++;
+            float eL, eR;
+            const bool hL = boxTest({ a.x, a.y, a.z }, { a.w, b.x, b.y }, r.o, r.inv, r.tmax, eL);
+            const bool hR = boxTest({ b.z, b.w, c.x }, { c.y, c.z, c.w }, r.o, r.inv, r.tmax, eR);
+            if (hL && hR) {
+                // nearer child first; on a tie the right child, as in src/bvh.cpp:301-307
+                const bool leftFirst = eL < eR;
+                push(r, leftFirst ? refs.y : refs.x);
+                r.cur = leftFirst ? refs.x : refs.y;
+            } else if (hL) {
+                r.cur = refs.x;
+            } else if (hR) {
+                r.cur = refs.y;
+            } else {
+                r.cur = pop(r);
+            }
+        }
+        // ---- leaf: every primitive of the leaf, in order (src/bvh.cpp:272-279)
+        if (r.cur != kRefNone) {
+            const uint32_t off = r.cur & kLeafOffsetMask;
+            const uint32_t cnt = (r.cur >> 27) & 15u;
+            bool done = false;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const TriRec tr = loadTri(sc.tris, off + i);
+                float t;
+                if (STATS)
+                    r.nTris++;
+                if (triangleTest(tr, r.o, r.d, r.tmax, t)) {
+                    r.tmax = t;
+                    r.hitPrim = (int)(off + i);
+                    // Binary visibility only asks whether the closest hit lies more
+                    // than 1e-4 before the target (src/light.cpp:101-104); any hit
+                    // that does settles it, the closest one is at least as near.
+                    if (r.kind == K_SHADOW_ANY && fabsf(t - r.slen) > 0.0001f) {
+                        done = true;
+                        break;
+                    }
+                }
+            }
+            r.cur = done ? kRefNone : pop(r);
+        }
+        if (r.cur == kRefNone)
+            r.active = false;
+    }
+
+    // Spheres are tested after the BVH, in order, against the current ray.t
+    // (src/bvh.cpp:354-355); a sphere hit is recorded as -2 - index.
+    __device__ __forceinline__ void spheres(RayState& r) const
+    {
+        for (int s = 0; s < sc.nSpheres; s++) {
+            float t;
+            if (sphereTest(sc.spheres[s], r.o, r.d, r.tmax, t)) {
+                r.tmax = t;
+                r.hitPrim = -2 - s;
+            }
+        }
+    }
+};
+
+// What updateHitInfo (src/bvh.cpp:18-48) and sampleMaterialKd
+// (src/shading.cpp:13-24) leave behind for the accepted closest hit.
+struct HitCtx {
+    f3 P, N, kd, mkd, ks;
+    float shin, tr;
+};
+
+__device__ __forceinline__ HitCtx shadeHit(const DevScene& sc, const DevFeat& ft, const RayState& r)
+{
+    HitCtx h;
+    h.P = r.o + r.tmax * r.d;
+    DevMaterial m;
+    if (r.hitPrim >= 0) {
+        const uint32_t i = (uint32_t)r.hitPrim;
+        const TriRec tr = loadTri(sc.tris, i);
+        const float4 a0 = sc.attrs[4u * i + 0], a1 = sc.attrs[4u * i + 1], a2 = sc.attrs[4u * i + 2], a3 = sc.attrs[4u * i + 3];
+        m = sc.mats[__float_as_uint(a3.w)];
+        f3 N = tr.n;
+        f2 uv = { 0.0f, 0.0f };
+        if (ft.normalInterp || ft.texMapping) {
+            // computeBarycentricCoord, src/interpolate.cpp:13-24
+            const f3 n = cross(tr.v1 - tr.v0, tr.v2 - tr.v0);
+            const f3 na = cross(tr.v2 - tr.v1, h.P - tr.v1);
+            const f3 nb = cross(tr.v0 - tr.v2, h.P - tr.v2);
+            const float alpha = dot(n, na) / dot(n, n);
+            const float beta = dot(n, nb) / dot(n, n);
+            const float gamma = 1.0f - alpha - beta;
+            if (ft.normalInterp) // src/interpolate.cpp:34-40
+                N = alpha * mk3(a0.x, a0.y, a0.z) + beta * mk3(a0.w, a1.x, a1.y) + gamma * mk3(a1.z, a1.w, a2.x);
+            if (ft.texMapping) { // src/interpolate.cpp:50-55
+                uv.x = a2.y * alpha + a2.w * beta + a3.y * gamma;
+                uv.y = a2.z * alpha + a3.x * beta + a3.z * gamma;
+            }
+        }
+        if (dot(r.d, tr.n) > 0.0f)
+            N = -N;
+        h.N = N;
+        h.kd = (ft.texMapping && m.tex >= 0) ? sampleTexture(sc, m.tex, uv, ft.bilinear != 0) : ld3(m.kd);
+    } else {
+        const DevSphere s = sc.spheres[-2 - r.hitPrim];
+        m = sc.mats[s.material];
+        h.N = normalize(h.P - ld3(s.center));
+        h.kd = ld3(m.kd);
+    }
+    h.mkd = ld3(m.kd);
+    h.ks = ld3(m.ks);
+    h.shin = m.shininess;
+    h.tr = m.transparency;
+    return h;
+}
+
+// generateReflectionRay, src/recursive.cpp:72-89
+__device__ __forceinline__ void reflectionRay(const f3& P, const f3& rd, const f3& N, f3& o, f3& d)
+{
+    const f3 nd = normalize(rd);
+    d = normalize(nd - 2.0f * dot(nd, N) * N);
+    o = P + N * 1.0e-5f;
+}
+
+// Camera ray i of pixel (px, py): generatePixelRays* (src/render.cpp:56-131)
+// plus the lens fan-out of src/extra.cpp:48-81.  sPix / sLens are the sampler
+// cursors of the pixel-sample and lens stretches of the pixel's stream; `pof`
+// carries the point of focus from a camera ray to its lens samples.
+template <bool DOF>
+__device__ __forceinline__ void cameraRay(const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, int px, int py,
+    uint32_t rayI, uint32_t& sPix, uint32_t& sLens, f3& pof, f3& o, f3& d)
+{
+    const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
+    const uint32_t c = rayI / dofN;
+    f3 dir = { 0.0f, 0.0f, 0.0f };
+    if (!(DOF && ft.dof) || (rayI % dofN) == 0) {
+        float ndcX, ndcY;
+        const float W = (float)fr.width, H = (float)fr.height;
+        if (ft.spp > 1) {
+            if (ft.jitter) {
+                const int p = (int)(c / ft.jitterN), q = (int)(c % ft.jitterN);
+                const float a = next1d(sPix);
+                const float b = next1d(sPix);
+                const float jx = (float)px + ((float)p + a) / (float)ft.jitterN;
+                const float jy = (float)py + ((float)q + b) / (float)ft.jitterN;
+                ndcX = jx / W * 2.0f - 1.0f;
+                ndcY = jy / H * 2.0f - 1.0f;
+            } else {
+                const float a = next1d(sPix);
+                const float b = next1d(sPix);
+                ndcX = ((float)px + a) / W * 2.0f - 1.0f;
+                ndcY = ((float)py + b) / H * 2.0f - 1.0f;
+            }
+        } else {
+            ndcX = ((float)px + 0.5f) / W * 2.0f - 1.0f;
+            ndcY = ((float)py + 0.5f) / H * 2.0f - 1.0f;
+        }
+        // Trackball::generateRay, framework/src/trackball.cpp:101-110
+        const f3 cd = normalize(mk3(-ndcX * cam.halfW, ndcY * cam.halfH, 1.0f));
+        dir = quatRotate(cam.qw, cam.q, cd);
+        if (DOF && ft.dof) { // getPointOfFocus, src/extra.cpp:15-23
+            const float cosAngle = dot(dir, cam.fwd);
+            const float curDistance = ft.dofDistance / cosAngle;
+            pof = cam.pos + curDistance * dir;
+        }
+    }
+    if (DOF && ft.dof) { // src/extra.cpp:27-44, :70-76
+        const float r0 = next1d(sLens);
+        const float r1 = next1d(sLens);
+        const float angle = r0 * kTwoPi;
+        const float dist = sqrtf(r1) * (ft.dofDiameter * 0.5f);
+        const float ox = cosf(angle) * dist;
+        const float oy = sinf(angle) * dist;
+        o = cam.pos + ox * cam.up + oy * cam.left;
+        d = normalize(pof - o);
+    } else {
+        o = cam.pos;
+        d = dir;
+    }
+}
+
+// Pixel of local work slot `slot` (64 consecutive slots = one 8x8 tile; tile k
+// of the frame belongs to shard k % nShard).  Returns false for the padding
+// pixels of partial edge tiles.
+__device__ __forceinline__ bool slotToPixel(const DevFrame& fr, uint32_t slot, int& px, int& py)
+{
+    const uint32_t tileLocal = slot >> 6, within = slot & 63u;
+    const uint32_t tile = tileLocal * (uint32_t)fr.nShard + (uint32_t)fr.shard;
+    const int tx = (int)(tile % (uint32_t)fr.tilesX), ty = (int)(tile / (uint32_t)fr.tilesX);
+    px = tx * kTile + (int)(within & 7u);
+    py = ty * kTile + (int)(within >> 3);
+    return px < fr.width && py < fr.height;
+}
+
+} // namespace rt

@@ -1,0 +1,508 @@
+// rt_wavefront.hip -- the queue-based (wavefront) form of renderImage for
+// gfx950, used whenever neither transparency nor glossy reflection is on.
+//
+// The reference consumes ONE Sampler stream per pixel, depth first
+// (src/render.cpp:34-39).  Which rays a pixel's ray tree contains, though, does
+// not depend on the draws: camera rays take their draws from fixed positions at
+// the head of the stream, reflection directions are pure geometry, and only
+// the light samples (src/light.cpp:205-253) draw from the rest, a fixed number
+// D per shaded hit.  So the position of every draw is known once the hits of
+// the pixel are counted: hit number k of the pixel (camera rays in order, each
+// chain root first) owns draws [main + D*k, main + D*(k+1)).  That turns the
+// frame into independent work items, each on its own lane:
+//
+//   1. pathKernel    one lane per camera ray: trace it and its mirror chain
+//                    (src/recursive.cpp:25-64), append one node per hit;
+//   2. prefixKernel  per pixel, exclusive prefix of its paths' hit counts;
+//   3. shadowKernel  one lane per (hit, light sample): jump the LCG to the
+//                    sample's draws, sample the light, trace the shadow ray
+//                    (any-hit), shade (src/light.cpp:166-186);
+//   4. combineKernel per pixel: sums, clamp and mirror combine in exactly the
+//                    reference's order of operations, then the pixel mean.
+//
+// Kernels 1 and 3 are persistent 64-lane wavefronts pulling batches of work
+// items from an atomic queue; lanes whose ray has finished take their next
+// item while the others keep traversing (rt_trace.hpp).  All arithmetic is the
+// same as in the per-pixel kernel of rt_kernels.hip, in the same order, so
+// both produce the same bits.
+
+#include "rt_trace.hpp"
+
+namespace rt {
+
+// One shaded hit.  A: what shading needs.  B: links and bookkeeping.
+struct NodeB {
+    uint32_t path; // path index inside the batch
+    int32_t depth;
+    int32_t child; // kChildNone, kChildMiss (value in cv), or node index
+    float cv[3];
+    uint32_t pad[2];
+};
+constexpr int32_t kChildNone = -1, kChildMiss = -2;
+constexpr int32_t kPathMiss = -1;
+
+struct WfBuffers {
+    int32_t* pathHead;   // [paths]  first node or kPathMiss
+    uint8_t* pathCount;  // [paths]  nodes of the path
+    uint32_t* pathBase;  // [paths]  nodes of earlier paths of the same pixel
+    float* pathEnv;      // [paths*3] environment colour of a camera ray that missed (env map on)
+    float4* nodeA;       // [nodes*4] P.xyz N.x | N.yz rd.xy | rd.z kd.xyz | ks.xyz shininess
+    NodeB* nodeB;        // [nodes]
+    float* contrib;      // [nodes * slots * 3]
+    uint32_t maxNodes;
+};
+
+struct WfParams {
+    uint32_t slotBegin;  // first local pixel slot of this batch
+    uint32_t nSlots;     // pixel slots in this batch (multiple of 64)
+    uint32_t R;          // camera rays per pixel
+    uint32_t slots;      // light-sample slots per hit: sum over lights of (point ? 1 : shadowSamples)
+    uint32_t drawsPerHit;
+    uint32_t pixDraws;   // draws of the pixel-sample stretch
+    uint32_t mainStart;  // position of the first light-sample draw
+    uint32_t chunk;      // work items per queue fetch
+};
+
+// state after k draws from `state` (src/sampler.h:18), O(log k)
+__device__ __forceinline__ uint32_t lcgSkip(uint32_t state, uint32_t k)
+{
+    uint32_t mul = 747796405u, add = 2891336453u;
+    while (k) {
+        if (k & 1u)
+            state = state * mul + add;
+        add = add * mul + add;
+        mul = mul * mul;
+        k >>= 1;
+    }
+    return state;
+}
+
+// Wave-level queue: every lane whose `want` is set receives the next work item
+// in `item`, or -1 when the queue is empty.  cursor/cend are wave-uniform.
+struct WaveQueue {
+    uint32_t cursor = 0, cend = 0;
+    bool exhausted = false;
+
+    __device__ __forceinline__ void fetch(bool& want, uint32_t& item, bool& dead, uint32_t* counter, uint32_t total, uint32_t chunk,
+        uint32_t lane)
+    {
+        for (;;) {
+            const unsigned long long wm = __ballot(want);
+            if (wm == 0ull)
+                return;
+            if (cursor == cend) {
+                if (exhausted) {
+                    if (want) {
+                        dead = true;
+                        want = false;
+                    }
+                    return;
+                }
+                uint32_t base = 0;
+                const int leader = __builtin_ctzll(wm);
+                if (lane == (uint32_t)leader)
+                    base = atomicAdd(counter, chunk);
+                base = __shfl(base, leader);
+                if (base >= total) {
+                    exhausted = true;
+                    continue;
+                }
+                cursor = base;
+                cend = (base + chunk < total) ? base + chunk : total;
+            }
+            const uint32_t rank = __popcll(wm & ((1ull << lane) - 1ull));
+            const uint32_t avail = cend - cursor;
+            const uint32_t nWant = __popcll(wm);
+            if (want && rank < avail) {
+                item = cursor + rank;
+                want = false;
+            }
+            cursor += (nWant < avail) ? nWant : avail;
+        }
+    }
+};
+
+__device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// 1. camera rays and their mirror chains
+// ---------------------------------------------------------------------------
+template <bool DOF, bool STATS>
+__global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevCamera cam, const DevFeat ft, const DevFrame fr,
+    const WfParams wp, const WfBuffers wb, DevCounters* __restrict__ ctr, int minActive)
+{
+    extern __shared__ uint32_t stackMem[];
+    const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x, blockDim.x };
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = wp.nSlots * wp.R;
+
+    RayState r;
+    r.active = false;
+    r.cur = kRefNone;
+    r.sp = 0;
+    r.nInner = r.nTris = 0;
+    uint32_t path = 0, nrays = 0;
+    int depth = 0, prev = -1, count = 0;
+    bool have = false, dead = false;
+    WaveQueue q;
+
+    for (;;) {
+        // ---- lanes without a path take the next one and shoot its camera ray
+        for (int round = 0; round < 2; round++) {
+            bool want = !have && !dead;
+            q.fetch(want, path, dead, &ctr->next, total, wp.chunk, lane);
+            if (!have && !dead && !want) {
+                const uint32_t slot = wp.slotBegin + path / wp.R, i = path % wp.R;
+                int px, py;
+                if (slotToPixel(fr, slot, px, py)) {
+                    const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
+                    const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
+                    uint32_t sPix = (ft.spp > 1) ? lcgSkip(seed, 2u * (i / dofN)) : seed;
+                    uint32_t sLens = (DOF && ft.dof) ? lcgSkip(seed, wp.pixDraws + 2u * i) : seed;
+                    f3 pof = { 0.0f, 0.0f, 0.0f }, o, d;
+                    cameraRay<DOF>(cam, ft, fr, px, py, i - (i % dofN), sPix, sLens, pof, o, d);
+                    tracer.launch(r, o, d, kFltMax, K_RADIANCE);
+                    nrays++;
+                    have = true;
+                    depth = 0;
+                    prev = -1;
+                    count = 0;
+                }
+                // padding pixel of a partial edge tile: nothing to do, take another path
+            }
+            // ---- paths whose ray has finished: record the hit, continue the chain or retire
+            while (have && !r.active) {
+                if (sc.nSpheres)
+                    tracer.spheres(r);
+                if (r.hitPrim == kHitNone) { // src/recursive.cpp:29-32
+                    const f3 env = sampleEnvironmentMap(sc, ft, r.d);
+                    if (depth == 0) {
+                        wb.pathHead[path] = kPathMiss;
+                        if (ft.envMap) {
+                            wb.pathEnv[3u * path + 0] = env.x;
+                            wb.pathEnv[3u * path + 1] = env.y;
+                            wb.pathEnv[3u * path + 2] = env.z;
+                        }
+                    } else {
+                        NodeB& pb = wb.nodeB[prev];
+                        pb.child = kChildMiss;
+                        pb.cv[0] = env.x, pb.cv[1] = env.y, pb.cv[2] = env.z;
+                    }
+                    wb.pathCount[path] = (uint8_t)count;
+                    have = false;
+                    break;
+                }
+                const HitCtx h = shadeHit(sc, ft, r);
+                // one node per shaded hit; slots are handed out per wave
+                const unsigned long long am = __ballot(true);
+                const int leader = __builtin_ctzll(am);
+                uint32_t base = 0;
+                if (lane == (uint32_t)leader)
+                    base = atomicAdd(&ctr->nodes, (uint32_t)__popcll(am));
+                const uint32_t idx = __shfl(base, leader) + __popcll(am & ((1ull << lane) - 1ull));
+                if (idx >= wb.maxNodes) { // cannot happen: the pool holds the worst case of the batch
+                    wb.pathCount[path] = (uint8_t)count;
+                    have = false;
+                    break;
+                }
+                float4* a = wb.nodeA + 4u * (size_t)idx;
+                a[0] = make_float4(h.P.x, h.P.y, h.P.z, h.N.x);
+                a[1] = make_float4(h.N.y, h.N.z, r.d.x, r.d.y);
+                a[2] = make_float4(r.d.z, h.kd.x, h.kd.y, h.kd.z);
+                a[3] = make_float4(h.ks.x, h.ks.y, h.ks.z, h.shin);
+                NodeB nb;
+                nb.path = path;
+                nb.depth = depth;
+                nb.child = kChildNone;
+                nb.cv[0] = nb.cv[1] = nb.cv[2] = 0.0f;
+                nb.pad[0] = nb.pad[1] = 0u;
+                wb.nodeB[idx] = nb;
+                if (depth == 0)
+                    wb.pathHead[path] = (int32_t)idx;
+                else
+                    wb.nodeB[prev].child = (int32_t)idx;
+                count++;
+                const bool reflective = !(h.ks.x == 0.0f && h.ks.y == 0.0f && h.ks.z == 0.0f);
+                if (depth < ft.maxDepth && ft.reflections && reflective) { // src/recursive.cpp:43-50
+                    f3 o, d;
+                    reflectionRay(h.P, r.d, h.N, o, d);
+                    tracer.launch(r, o, d, kFltMax, K_RADIANCE);
+                    nrays++;
+                    prev = (int)idx;
+                    depth++;
+                } else {
+                    wb.pathCount[path] = (uint8_t)count;
+                    have = false;
+                    break;
+                }
+            }
+            if (__ballot(!have && !dead) == 0ull)
+                break;
+        }
+        if (__ballot(r.active && have) == 0ull) {
+            if (__ballot(!dead) == 0ull)
+                break;
+            continue;
+        }
+        tracer.run(r, q.exhausted ? 0 : minActive);
+    }
+
+    const unsigned long long rs = waveSum(nrays), ni = waveSum(r.nInner), nt = waveSum(r.nTris);
+    if (lane == 0) {
+        atomicAdd(&ctr->rays, rs);
+        if (STATS) {
+            atomicAdd(&ctr->inner, ni);
+            atomicAdd(&ctr->tris, nt);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 2. per pixel: how many hits precede each of its paths
+// ---------------------------------------------------------------------------
+__global__ void prefixKernel(const DevFrame fr, const WfParams wp, const WfBuffers wb)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= wp.nSlots)
+        return;
+    int px, py;
+    if (!slotToPixel(fr, wp.slotBegin + s, px, py))
+        return;
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < wp.R; i++) {
+        const uint32_t path = s * wp.R + i;
+        wb.pathBase[path] = base;
+        base += wb.pathCount[path];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 3. one light sample of one hit: computeContributionPointLight, src/light.cpp:166-186
+// ---------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void shadowKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp,
+    const WfBuffers wb, DevCounters* __restrict__ ctr, int minActive)
+{
+    extern __shared__ uint32_t stackMem[];
+    const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x, blockDim.x };
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
+    const uint32_t total = nNodes * wp.slots; // host guarantees maxNodes * slots < 2^32
+
+    RayState r;
+    r.active = false;
+    r.cur = kRefNone;
+    r.sp = 0;
+    r.nInner = r.nTris = 0;
+    uint32_t item = 0, nrays = 0;
+    f3 lcol = { 0.0f, 0.0f, 0.0f };
+    bool have = false, dead = false;
+    WaveQueue q;
+
+    for (;;) {
+        for (int round = 0; round < 2; round++) {
+            bool want = !have && !dead;
+            q.fetch(want, item, dead, &ctr->nextShadow, total, wp.chunk, lane);
+            if (!have && !dead && !want) {
+                const uint32_t node = item / wp.slots;
+                uint32_t slot = item % wp.slots;
+                // which light and which of its samples; draws consumed by the lights before it
+                int l = 0;
+                uint32_t drawPrefix = 0, perSample = 0;
+                for (; l < sc.nLights; l++) {
+                    const int type = sc.lights[l].type;
+                    const uint32_t n = (type == 0) ? 1u : ft.shadowSamples;
+                    perSample = (type == 0) ? 0u : (type == 1 ? 1u : 2u);
+                    if (slot < n)
+                        break;
+                    slot -= n;
+                    drawPrefix += n * perSample;
+                }
+                const NodeB nb = wb.nodeB[node];
+                const float4 a0 = wb.nodeA[4u * (size_t)node];
+                const f3 P = { a0.x, a0.y, a0.z };
+                int px, py;
+                slotToPixel(fr, wp.slotBegin + nb.path / wp.R, px, py);
+                const uint32_t seed = (uint32_t)(fr.height * px + py);
+                const uint32_t hitOrdinal = wb.pathBase[nb.path] + (uint32_t)nb.depth;
+                uint32_t s = lcgSkip(seed, wp.mainStart + wp.drawsPerHit * hitOrdinal + drawPrefix + slot * perSample);
+                const rt_light& light = sc.lights[l];
+                f3 pos, col;
+                if (light.type == 0) {
+                    pos = ld3(light.v + 0);
+                    col = ld3(light.v + 3);
+                } else if (light.type == 1) {
+                    sampleSegmentLight(next1d(s), light, pos, col);
+                } else {
+                    const float sx = next1d(s);
+                    const float sy = next1d(s);
+                    sampleParallelogramLight({ sx, sy }, light, pos, col);
+                }
+                lcol = col;
+                have = true;
+                if (ft.shadows) { // src/light.cpp:94-97
+                    const f3 toHit = P - pos;
+                    tracer.launch(r, pos, normalize(toHit), length(toHit), K_SHADOW_ANY);
+                    nrays++;
+                } else { // src/light.cpp:270-272: no ray; keep the direction to the light in r.d
+                    r.active = false;
+                    r.hitPrim = kHitNone;
+                    r.d = -normalize(pos - P);
+                }
+            }
+            if (have && !r.active) {
+                if (ft.shadows && sc.nSpheres)
+                    tracer.spheres(r);
+                const bool visible = (r.hitPrim == kHitNone) ? true : (fabsf(r.tmax - r.slen) <= 0.0001f); // src/light.cpp:101-107
+                f3 c = { 0.0f, 0.0f, 0.0f };
+                const f3 vis = visible ? lcol : mk3(0.0f);
+                if (!isZero(vis)) { // src/light.cpp:171-186
+                    const uint32_t node = item / wp.slots;
+                    const float4* a = wb.nodeA + 4u * (size_t)node;
+                    const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+                    const f3 N = { a0.w, a1.x, a1.y }, rd = { a1.z, a1.w, a2.x }, kd = { a2.y, a2.z, a2.w }, ks = { a3.x, a3.y, a3.z };
+                    c = computeShading(ft, N, kd, ks, a3.w, -rd, -r.d, vis);
+                }
+                float* dst = wb.contrib + 3u * (size_t)item;
+                dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
+                have = false;
+            }
+            if (__ballot(!have && !dead) == 0ull)
+                break;
+        }
+        if (__ballot(r.active && have) == 0ull) {
+            if (__ballot(!dead) == 0ull)
+                break;
+            continue;
+        }
+        tracer.run(r, q.exhausted ? 0 : minActive);
+    }
+
+    const unsigned long long rs = waveSum(nrays), ni = waveSum(r.nInner), nt = waveSum(r.nTris);
+    if (lane == 0) {
+        atomicAdd(&ctr->rays, rs);
+        if (STATS) {
+            atomicAdd(&ctr->inner, ni);
+            atomicAdd(&ctr->tris, nt);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 4. per pixel: computeLightContribution's sums and clamp (src/light.cpp:283-298),
+//    the mirror combine (src/recursive.cpp:126) and renderRays' mean (:10-17)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ f3 nodeLo(const DevScene& sc, const DevFeat& ft, const WfBuffers& wb, uint32_t node, uint32_t slots)
+{
+    const float* c = wb.contrib + 3u * (size_t)node * slots;
+    f3 Lo = mk3(0.0f);
+    for (int l = 0; l < sc.nLights; l++) {
+        if (sc.lights[l].type == 0) {
+            Lo = Lo + (mk3(0.0f) + ld3(c));
+            c += 3;
+        } else {
+            f3 acc = mk3(0.0f);
+            for (uint32_t s = 0; s < ft.shadowSamples; s++) {
+                acc = acc + ld3(c);
+                c += 3;
+            }
+            Lo = Lo + acc * (1.0f / (float)ft.shadowSamples);
+        }
+    }
+    return clamp01(Lo);
+}
+
+__global__ void combineKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp, const WfBuffers wb,
+    float* __restrict__ out)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= wp.nSlots)
+        return;
+    int px, py;
+    if (!slotToPixel(fr, wp.slotBegin + s, px, py))
+        return;
+    f3 L = mk3(0.0f);
+    for (uint32_t i = 0; i < wp.R; i++) {
+        const uint32_t path = s * wp.R + i;
+        const int32_t head = wb.pathHead[path];
+        f3 v;
+        if (head == kPathMiss) {
+            v = ft.envMap ? ld3(wb.pathEnv + 3u * path) : mk3(0.0f);
+        } else {
+            int32_t chain[kMaxDepth + 1];
+            int n = 0;
+            int32_t cur = head, link = kChildNone;
+            f3 cv = mk3(0.0f);
+            while (n <= kMaxDepth) {
+                chain[n++] = cur;
+                const NodeB nb = wb.nodeB[cur];
+                link = nb.child;
+                cv = ld3(nb.cv);
+                if (link < 0)
+                    break;
+                cur = link;
+            }
+            // deepest hit first
+            v = nodeLo(sc, ft, wb, (uint32_t)chain[n - 1], wp.slots);
+            if (link == kChildMiss) {
+                const float4 a3 = wb.nodeA[4u * (size_t)chain[n - 1] + 3];
+                v = v + cv * mk3(a3.x, a3.y, a3.z);
+            }
+            for (int k = n - 2; k >= 0; k--) {
+                const float4 a3 = wb.nodeA[4u * (size_t)chain[k] + 3];
+                v = nodeLo(sc, ft, wb, (uint32_t)chain[k], wp.slots) + v * mk3(a3.x, a3.y, a3.z);
+            }
+        }
+        L = L + v;
+    }
+    const f3 c = L / (float)wp.R;
+    const uint32_t slot = wp.slotBegin + s;
+    const size_t idx = fr.packed ? (size_t)slot : ((size_t)(fr.height - 1 - py) * fr.width + px);
+    out[3 * idx + 0] = c.x;
+    out[3 * idx + 1] = c.y;
+    out[3 * idx + 2] = c.z;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+typedef void (*PathFn)(const DevScene, const DevCamera, const DevFeat, const DevFrame, const WfParams, const WfBuffers,
+    DevCounters*, int);
+typedef void (*ShadowFn)(const DevScene, const DevFeat, const DevFrame, const WfParams, const WfBuffers, DevCounters*, int);
+
+static PathFn pathVariant(bool dof, bool stats)
+{
+    if (dof)
+        return stats ? pathKernel<true, true> : pathKernel<true, false>;
+    return stats ? pathKernel<false, true> : pathKernel<false, false>;
+}
+static ShadowFn shadowVariant(bool stats) { return stats ? shadowKernel<true> : shadowKernel<false>; }
+
+hipError_t wavefrontOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks)
+{
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(pathBlocks, pathVariant(dof, stats), blockThreads, ldsBytes);
+    if (e != hipSuccess)
+        return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(shadowBlocks, shadowVariant(stats), blockThreads, ldsBytes);
+}
+
+hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
+    hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
+    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive)
+{
+    hipLaunchKernelGGL(pathVariant(dof, stats), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, cam, ft, fr, wp, wb,
+        ctr, minActive);
+    const int pb = (int)((wp.nSlots + 255) / 256);
+    hipLaunchKernelGGL(prefixKernel, dim3(pb), dim3(256), 0, stream, fr, wp, wb);
+    hipLaunchKernelGGL(shadowVariant(stats), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, fr, wp, wb, ctr,
+        minActive);
+    hipLaunchKernelGGL(combineKernel, dim3(pb), dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
+    return hipGetLastError();
+}
+
+} // namespace rt
