@@ -162,19 +162,20 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    st = ctx.sync(sptr)  # rays of the last launch, summed kernel time of the timed launches
-    kernel_ms = st["kernel_ms"] / max(1, st["launches"])
+    st = ctx.sync(sptr)  # rays of the last launch, summed kernel times of the timed launches
+    nl = max(1, st["launches"])
+    frame_ms, path_ms, shadow_ms = st["kernel_ms"] / nl, st["path_ms"] / nl, st["shadow_ms"] / nl
 
     rays_local = float(st["rays"])
-    t_all = torch.tensor([dt, rays_local, kernel_ms], dtype=torch.float64, device=dev)
+    t_all = torch.tensor([dt, rays_local], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t_all.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t_all.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, rays_total, kernel_ms_max = float(tmax[0]), float(tsum[1]), float(tmax[2])
+        dt_max, rays_total = float(tmax[0]), float(tsum[1])
     else:
-        dt_max, rays_total, kernel_ms_max = dt, rays_local, kernel_ms
+        dt_max, rays_total = dt, rays_local
 
     # one more launch with the node / triangle counters on (outside the timed region)
     tmp = packed if world > 1 else frame
@@ -184,30 +185,42 @@ def main():
     if rank == 0:
         ms_per_step = dt_max / args.steps * 1e3
         value = rays_total * args.steps / dt_max / 1e6
-        # Algorithmic traffic of one launch of the dominant (render) kernel on this rank:
-        # 64 B per sibling-pair record fetched, 36 B of vertex positions per triangle
-        # tested, 28 B ray + 16 B hit record per ray.
-        alg_bytes = 64.0 * cst["inner_nodes"] + 36.0 * cst["tri_tests"] + 44.0 * cst["rays"]
-        alg_flops = 26.0 * (cst["rays"] + 2.0 * cst["inner_nodes"]) + 50.0 * cst["tri_tests"]
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # Dominant kernel: the shadow-ray kernel of the wavefront path (the whole per-pixel
+        # kernel when a frame has to take that path).  Algorithmic traffic of one launch on
+        # this rank: 64 B per sibling-pair record fetched, 36 B of vertex positions per
+        # triangle tested, 28 B ray + 16 B hit record per ray.
+        if shadow_ms > 0:
+            kname, k_ms = "shadowKernel", shadow_ms
+            k_rays, k_inner, k_tris = cst["shadow_rays"], cst["shadow_inner_nodes"], cst["shadow_tri_tests"]
+        else:
+            kname, k_ms = "renderKernel", frame_ms
+            k_rays, k_inner, k_tris = cst["rays"], cst["inner_nodes"], cst["tri_tests"]
+        alg_bytes = 64.0 * k_inner + 36.0 * k_tris + 44.0 * k_rays
+        alg_flops = 26.0 * (k_rays + 2.0 * k_inner) + 50.0 * k_tris
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        tflops = alg_flops / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "Mrays/s (whole node) on dragon.obj 1080p 16spp; ms/frame" if args.workload == "dragon"
                       else f"Mrays/s ({args.workload})",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "rays_per_frame": int(rays_total), "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)",
+            "config": {"workload": desc, "rays_per_frame": int(rays_total),
+                       "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)",
                        "scene_note": "dragon.obj is absent from the reference snapshot; procedural stand-in with the same triangle count"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "renderKernel", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": kname, "kernel_ms": round(k_ms, 4),
+                         "kernel_rays_per_launch": int(k_rays),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_ray": round(alg_bytes / max(1.0, cst["rays"]), 2),
-                         "inner_nodes_per_ray": round(cst["inner_nodes"] / max(1.0, cst["rays"]), 3),
-                         "tri_tests_per_ray": round(cst["tri_tests"] / max(1.0, cst["rays"]), 3),
-                         "fp32": {"achieved_tflops": round(alg_flops / (kernel_ms * 1e-3) / 1e12, 4),
-                                  "peak_tflops": FP32_PEAK_TFLOPS,
-                                  "frac": round(alg_flops / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5)}},
+                         "bytes_per_ray": round(alg_bytes / max(1.0, k_rays), 2),
+                         "inner_nodes_per_ray": round(k_inner / max(1.0, k_rays), 3),
+                         "tri_tests_per_ray": round(k_tris / max(1.0, k_rays), 3),
+                         "kernel_mrays_per_s": round(k_rays / (k_ms * 1e-3) / 1e6, 1),
+                         "fp32": {"achieved_tflops": round(tflops, 4), "peak_tflops": FP32_PEAK_TFLOPS,
+                                  "frac": round(tflops / FP32_PEAK_TFLOPS, 5)},
+                         "frame_device_ms": {"all_kernels": round(frame_ms, 4), "pathKernel": round(path_ms, 4),
+                                             "shadowKernel": round(shadow_ms, 4)}},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(scene, features, width, height, args.cpu_scale)

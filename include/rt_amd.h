@@ -159,6 +159,12 @@ typedef struct {
     float total_ms;       /* wall time of the call */
     uint32_t launches;    /* render launches kernel_ms covers */
     uint32_t reserved;
+    /* the share of the shadow-ray kernel (wavefront path; zero on the per-pixel path) */
+    uint64_t shadow_rays;
+    uint64_t shadow_inner_nodes;
+    uint64_t shadow_tri_tests;
+    float path_ms;        /* camera-ray / mirror-chain kernel, summed like kernel_ms */
+    float shadow_ms;      /* shadow-ray kernel, summed like kernel_ms */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

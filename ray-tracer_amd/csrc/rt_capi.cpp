@@ -45,6 +45,8 @@ struct WfBuffers {
     float4* nodeA;
     NodeB* nodeB;
     float* contrib;
+    float4* srays;
+    uint8_t* svis;
     uint32_t maxNodes;
 };
 struct WfParams {
@@ -53,7 +55,7 @@ struct WfParams {
 hipError_t wavefrontOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
 hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
-    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive);
+    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, hipEvent_t* marks, int numCU);
 } // namespace rt
 
 using namespace rt;
@@ -65,7 +67,7 @@ struct rt_ctx {
     int numCU = 256;
     std::string error;
     // device buffers
-    float4* dPairs = nullptr;
+    uint4* dPairs = nullptr;
     float4* dTris = nullptr;
     float4* dAttrs = nullptr;
     DevMaterial* dMats = nullptr;
@@ -78,8 +80,11 @@ struct rt_ctx {
     DevCounters* dCounters = nullptr;
     float* dFrame = nullptr;
     size_t frameCap = 0;
-    // one HIP event pair per render launch since the last stats read
+    // five HIP events per render launch since the last stats read: start, after the path
+    // kernel, before and after the shadow kernel, end (the middle three only on the
+    // wavefront path, first batch)
     std::vector<hipEvent_t> evPool;
+    std::vector<uint8_t> evHasMarks;
     size_t evUsed = 0;
     DevScene scene {};
     bool haveScene = false;
@@ -88,14 +93,14 @@ struct rt_ctx {
     rt_features features {};
     bool haveFeatures = false;
     // tuning knobs of the render kernel (environment-overridable for experiments)
-    int minActive = 40;
+    int minActive = 32;
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
     int forcePerPixel = 0; // 1 = always use the per-pixel kernel
     size_t workspaceCap = 64ull << 30; // bytes the wavefront path may hold
     // wavefront workspace (grow-only)
-    void* wsPtr[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    size_t wsBytes[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    void* wsPtr[10] = {};
+    size_t wsBytes[10] = {};
 };
 
 static int fail(rt_ctx* ctx, int code, const char* fmt, ...)
@@ -391,20 +396,46 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
         return static_cast<uint32_t>(pairIndex[child]);
     };
 
-    std::vector<float4> pairs(innerOrder.size() * 4);
+    // Quantisation grid: 65535 cells per axis across the root box.  A plane q stands
+    // for the real number gridMin + q * gridCell (both floats); lower planes round
+    // down, upper planes round up, checked in double so the quantised box contains
+    // the float box whatever the rounding of the division did.
+    const rt_node& rootNode = nodes[0];
+    float gridMin[3], gridCell[3];
+    for (int a = 0; a < 3; a++) {
+        gridMin[a] = rootNode.lower[a];
+        const double ext = static_cast<double>(rootNode.upper[a]) - static_cast<double>(rootNode.lower[a]);
+        gridCell[a] = (ext > 0.0 && std::isfinite(ext)) ? static_cast<float>(ext / 65535.0) : 0.0f;
+    }
+    auto quantLo = [&](float v, int a) -> uint32_t {
+        if (!(gridCell[a] > 0.0f))
+            return 0u;
+        double q = std::floor((static_cast<double>(v) - gridMin[a]) / gridCell[a]);
+        q = std::min(65535.0, std::max(0.0, q));
+        while (q > 0.0 && static_cast<double>(gridMin[a]) + q * gridCell[a] > static_cast<double>(v))
+            q -= 1.0;
+        return static_cast<uint32_t>(q);
+    };
+    auto quantHi = [&](float v, int a) -> uint32_t {
+        if (!(gridCell[a] > 0.0f))
+            return 65535u; // flat or empty axis: A = 0, every plane sits at gridMin
+        double q = std::ceil((static_cast<double>(v) - gridMin[a]) / gridCell[a]);
+        q = std::min(65535.0, std::max(0.0, q));
+        while (q < 65535.0 && static_cast<double>(gridMin[a]) + q * gridCell[a] < static_cast<double>(v))
+            q += 1.0;
+        return static_cast<uint32_t>(q);
+    };
+    std::vector<uint4> pairs(innerOrder.size() * 2);
     for (size_t k = 0; k < innerOrder.size(); k++) {
         const rt_node& nd = nodes[innerOrder[k]];
-        const rt_node& l = nodes[nd.data[0]];
-        const rt_node& r = nodes[nd.data[1]];
-        float4* p = &pairs[4 * k];
-        p[0] = make_float4(l.lower[0], l.lower[1], l.lower[2], l.upper[0]);
-        p[1] = make_float4(l.upper[1], l.upper[2], r.lower[0], r.lower[1]);
-        p[2] = make_float4(r.lower[2], r.upper[0], r.upper[1], r.upper[2]);
-        const uint32_t rl = childRef(nd.data[0]), rr = childRef(nd.data[1]);
-        float fl, frr;
-        std::memcpy(&fl, &rl, 4);
-        std::memcpy(&frr, &rr, 4);
-        p[3] = make_float4(fl, frr, 0.0f, 0.0f);
+        const rt_node* ch[2] = { &nodes[nd.data[0]], &nodes[nd.data[1]] };
+        uint32_t w[2][3];
+        for (int c = 0; c < 2; c++)
+            for (int a = 0; a < 3; a++)
+                w[c][a] = quantLo(ch[c]->lower[a], a) | (quantHi(ch[c]->upper[a], a) << 16);
+        uint4* p = &pairs[2 * k];
+        p[0] = make_uint4(w[0][0], w[0][1], w[0][2], w[1][0]);
+        p[1] = make_uint4(w[1][1], w[1][2], childRef(nd.data[0]), childRef(nd.data[1]));
     }
 
     std::vector<float4> tris(static_cast<size_t>(n_prims) * 6), attrs(static_cast<size_t>(n_prims) * 4);
@@ -495,6 +526,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
     s.rootRef = (root.data[0] & RT_LEAF_BIT) ? (kLeafFlag | (root.data[1] << 27) | (root.data[0] & ~RT_LEAF_BIT)) : 0u;
     std::memcpy(s.rootLo, root.lower, 12);
     std::memcpy(s.rootHi, root.upper, 12);
+    std::memcpy(s.gridMin, gridMin, 12);
+    std::memcpy(s.gridCell, gridCell, 12);
     s.nPrims = n_prims;
     s.nMeshes = static_cast<int32_t>(n_meshes);
     s.nSpheres = static_cast<int32_t>(n_spheres);
@@ -655,18 +688,20 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, sizeof(DevCounters), stream));
     if (timeIt) {
-        if (ctx->evUsed + 2 > ctx->evPool.size()) {
-            if (ctx->evPool.size() >= 8192) { // unread launches pile up: fold them by waiting once
+        if (ctx->evUsed + 5 > ctx->evPool.size()) {
+            if (ctx->evPool.size() >= 5 * 4096) { // unread launches pile up: fold them by waiting once
                 HIP_TRY(ctx, hipStreamSynchronize(stream));
                 ctx->evUsed = 0;
             } else {
-                hipEvent_t a, b;
-                HIP_TRY(ctx, hipEventCreate(&a));
-                HIP_TRY(ctx, hipEventCreate(&b));
-                ctx->evPool.push_back(a);
-                ctx->evPool.push_back(b);
+                for (int i = 0; i < 5; i++) {
+                    hipEvent_t a;
+                    HIP_TRY(ctx, hipEventCreate(&a));
+                    ctx->evPool.push_back(a);
+                }
+                ctx->evHasMarks.push_back(0);
             }
         }
+        ctx->evHasMarks[ctx->evUsed / 5] = 0;
         HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed], stream));
     }
 
@@ -712,7 +747,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
         const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * (F.enableReflections ? F.maxRayDepth + 1 : 1);
         const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + (F.enableEnvironmentMap ? 12 : 0))
-            + nodesPerPixel * (64 + sizeof(NodeB) + 12ull * std::max(1u, slots));
+            + nodesPerPixel * (64 + sizeof(NodeB) + (12ull + 48 + 1) * std::max(1u, slots));
         uint64_t batchSlots = ctx->workspaceCap / std::max<uint64_t>(1, bytesPerPixel);
         batchSlots = std::min<uint64_t>(batchSlots, 0x7fffffffull / wp.R);                                       // path index in 31 bits
         batchSlots = std::min<uint64_t>(batchSlots, 0xffffffffull / (nodesPerPixel * std::max(1u, slots)));      // item index in 32 bits
@@ -720,10 +755,11 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         if (batchSlots == 0)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: one tile of this frame needs more than the %zu-byte workspace", ctx->workspaceCap);
         const uint64_t paths = batchSlots * wp.R, maxNodes = batchSlots * nodesPerPixel;
-        const size_t want[7] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
+        const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, slots);
+        const size_t want[9] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
             F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
-            static_cast<size_t>(maxNodes) * sizeof(NodeB), static_cast<size_t>(maxNodes) * 12 * std::max(1u, slots) };
-        for (int i = 0; i < 7; i++) {
+            static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * 48, items };
+        for (int i = 0; i < 9; i++) {
             if (ctx->wsBytes[i] < want[i]) {
                 HIP_TRY(ctx, hipStreamSynchronize(stream));
                 if (ctx->wsPtr[i])
@@ -742,6 +778,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         wb.nodeA = static_cast<float4*>(ctx->wsPtr[4]);
         wb.nodeB = static_cast<NodeB*>(ctx->wsPtr[5]);
         wb.contrib = static_cast<float*>(ctx->wsPtr[6]);
+        wb.srays = static_cast<float4*>(ctx->wsPtr[7]);
+        wb.svis = static_cast<uint8_t*>(ctx->wsPtr[8]);
         wb.maxNodes = static_cast<uint32_t>(maxNodes);
 
         const bool dof = F.enableDepthOfField != 0;
@@ -759,13 +797,18 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             const uint64_t items = static_cast<uint64_t>(wp.nSlots) * wp.R;
             const int pathBlocks = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->numCU) * pathPerCU, (items + 255) / 256)));
             const int shadowBlocks = ctx->numCU * shadowPerCU;
+            hipEvent_t* marks = nullptr;
+            if (timeIt && begin == 0) {
+                marks = &ctx->evPool[ctx->evUsed + 1];
+                ctx->evHasMarks[ctx->evUsed / 5] = 1;
+            }
             HIP_TRY(ctx, launchWavefront(dof, collect, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
-                              wb, ctx->dCounters, dOut, ctx->minActive));
+                              wb, ctx->dCounters, dOut, ctx->minActive, marks, ctx->numCU));
         }
     }
     if (timeIt) {
-        HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed + 1], stream));
-        ctx->evUsed += 2;
+        HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed + 4], stream));
+        ctx->evUsed += 5;
     }
     return RT_OK;
 }
@@ -778,14 +821,23 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
         stats->rays = c.rays;
         stats->inner_nodes = c.inner;
         stats->tri_tests = c.tris;
-        stats->kernel_ms = 0.0f;
+        stats->shadow_rays = c.sRays;
+        stats->shadow_inner_nodes = c.sInner;
+        stats->shadow_tri_tests = c.sTris;
+        stats->kernel_ms = stats->path_ms = stats->shadow_ms = 0.0f;
         stats->launches = 0;
         if (timed) {
-            for (size_t i = 0; i + 1 < ctx->evUsed; i += 2) {
+            for (size_t i = 0; i + 4 < ctx->evUsed; i += 5) {
                 float ms = 0.0f;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]));
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 4]));
                 stats->kernel_ms += ms;
                 stats->launches++;
+                if (ctx->evHasMarks[i / 5]) {
+                    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]));
+                    stats->path_ms += ms;
+                    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i + 2], ctx->evPool[i + 3]));
+                    stats->shadow_ms += ms;
+                }
             }
         }
     }

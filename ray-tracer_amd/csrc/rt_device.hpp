@@ -69,10 +69,13 @@ RT_HD f3 quatRotate(float qw, f3 q, f3 v)
 // Device-resident scene (HBM; the whole working set of the bundled scenes is a
 // few MB and lives in L2 / Infinity Cache after the first touches).
 //
-// pairs : one 64-B record per inner node = both children's boxes + child refs,
-//         so one inner-node visit is one 64-B fetch (4 x dwordx4 per lane):
-//           [0] loL.xyz hiL.x  [1] hiL.yz loR.xy  [2] loR.z hiR.xyz
-//           [3] refL refR 0 0   (as uint bits)
+// pairs : one 32-B record per inner node = both children's boxes + child refs,
+//         so one inner-node visit is two 16-B fetches per lane.  Box planes are
+//         16-bit positions on a per-axis grid spanning the root box (plane =
+//         gridMin + q * gridCell), lower planes rounded down and upper planes
+//         rounded up, so a quantised box always contains the float box; the
+//         traversal only has to be conservative, the triangle test decides.
+//           [0] Lx Ly Lz Rx   [1] Ry Rz refL refR     each box dword = lo | hi << 16
 //         child ref: inner -> index of the child's own pair record;
 //                    leaf  -> kLeafFlag | count << 27 | offset   (count <= 15)
 // tris  : one 96-B record per primitive (6 x dwordx4), holding the
@@ -116,7 +119,7 @@ struct DevSphere {
 };
 
 struct DevScene {
-    const float4* pairs;
+    const uint4* pairs;
     const float4* tris;
     const float4* attrs;
     const DevMaterial* mats;
@@ -126,6 +129,7 @@ struct DevScene {
     const rt_light* lights;
     uint32_t rootRef;
     float rootLo[3], rootHi[3];
+    float gridMin[3], gridCell[3];
     uint32_t nPrims;
     int32_t nMeshes, nSpheres, nLights, nTex;
     int32_t env[6];
@@ -160,9 +164,10 @@ struct DevFrame {
 };
 
 struct DevCounters {
-    unsigned long long rays, inner, tris; // accumulated over the frame
+    unsigned long long rays, inner, tris;       // accumulated over the frame, all kernels
+    unsigned long long sRays, sInner, sTris;    // the shadow kernel's share of them
     // work-queue heads and the node allocator; cleared before every batch
-    uint32_t next, nextShadow, nodes, pad;
+    uint32_t next, nextShadow, nodes, shadowQueued;
 };
 
 // ----------------------------------------------------------------------------
@@ -394,6 +399,28 @@ __device__ __forceinline__ bool triangleTest(const TriRec& r, f3 o, f3 d, float 
     if (!(dot(r.E1, p - r.v1) >= 0.0f))
         return false;
     if (!(dot(r.E2, p - r.v2) >= 0.0f))
+        return false;
+    tOut = t;
+    return true;
+}
+
+// The same test reading the record in two steps: the 16-B plane first, the
+// remaining 80 B only for rays whose plane hit lies inside [0, tmax].
+__device__ __forceinline__ bool triangleTestLazy(const float4* __restrict__ tris, uint32_t i, f3 o, f3 d, float tmax, float& tOut)
+{
+    const float4* p4 = tris + 6u * i;
+    const float4 a = p4[0];
+    const f3 n = { a.x, a.y, a.z };
+    const float t = (a.w - dot(o, n)) / dot(d, n);
+    if (!(t >= 0.0f && t <= tmax))
+        return false;
+    const float4 b = p4[1], c = p4[2], e = p4[3], f = p4[4], g = p4[5];
+    const f3 p = o + d * t;
+    if (!(dot(mk3(b.x, b.y, b.z), p - mk3(b.w, c.x, c.y)) >= 0.0f))
+        return false;
+    if (!(dot(mk3(c.z, c.w, e.x), p - mk3(e.y, e.z, e.w)) >= 0.0f))
+        return false;
+    if (!(dot(mk3(f.x, f.y, f.z), p - mk3(f.w, g.x, g.y)) >= 0.0f))
         return false;
     tOut = t;
     return true;

@@ -16,7 +16,13 @@ constexpr float kFltMax = 3.402823466e+38f;
 constexpr float kTwoPi = 6.28318530717958647692528676655900576f;
 
 struct RayState {
-    f3 o, d, inv;
+    f3 o, d;
+    // Slab arithmetic against the quantised boxes: plane distance t = q * A + B per
+    // axis, B widened by the rounding bound of that expression (Bn for the plane the
+    // ray enters through, Bf for the one it leaves through); rot selects which half
+    // of a box dword is the entering plane (0 or 16 per axis, 5 bits each).
+    f3 A, Bn, Bf;
+    uint32_t rot;
     float tmax, slen; // current closest t; the ray's original length (shadow rays)
     int hitPrim;      // primitive index, kHitNone, or -2 - sphere index
     int kind;
@@ -58,7 +64,7 @@ struct Tracer {
     {
         r.o = o;
         r.d = d;
-        r.inv = rcp3(d);
+        const f3 inv = rcp3(d);
         r.tmax = tmax;
         r.slen = tmax;
         r.kind = kind;
@@ -69,9 +75,22 @@ struct Tracer {
         if (accel) {
             float e;
             const f3 lo = { sc.rootLo[0], sc.rootLo[1], sc.rootLo[2] }, hi = { sc.rootHi[0], sc.rootHi[1], sc.rootHi[2] };
-            if (sc.nPrims != 0 && boxTest(lo, hi, o, r.inv, kFltMax, e)) {
+            if (sc.nPrims != 0 && boxTest(lo, hi, o, inv, kFltMax, e)) {
                 r.cur = sc.rootRef;
                 r.active = true;
+                // t(q) = ((gridMin + q*cell) - o) * inv = q*A + B.  Rounding bound of the
+                // fused form: (|q*A| + |B|) * 2^-22 for the inputs plus half an ulp of
+                // the result; (extent*|inv| + |B|) * 2^-20 covers it with room to spare.
+                const f3 gmin = { sc.gridMin[0], sc.gridMin[1], sc.gridMin[2] };
+                const f3 cell = { sc.gridCell[0], sc.gridCell[1], sc.gridCell[2] };
+                r.A = cell * inv;
+                const f3 B = (gmin - o) * inv;
+                const float k = 9.5367431640625e-7f; // 2^-20
+                const f3 err = { (65535.0f * fabsf(r.A.x) + fabsf(B.x)) * k, (65535.0f * fabsf(r.A.y) + fabsf(B.y)) * k,
+                    (65535.0f * fabsf(r.A.z) + fabsf(B.z)) * k };
+                r.Bn = B - err;
+                r.Bf = B + err;
+                r.rot = (inv.x < 0.0f ? 16u : 0u) | (inv.y < 0.0f ? 16u << 5 : 0u) | (inv.z < 0.0f ? 16u << 10 : 0u);
             }
         } else {
             // enableAccelStructure off: every primitive in order (src/bvh.cpp:344-351)
@@ -86,6 +105,24 @@ struct Tracer {
                 }
             }
         }
+    }
+
+    // Conservative slab test against one quantised child box (three dwords, lo | hi << 16
+    // per axis).  Rotating a dword by the ray's per-axis amount puts the plane the ray
+    // enters through into the low half, so no min/max per axis is needed.  A NaN slab
+    // (zero direction component) drops out of the max/min, i.e. that axis is ignored,
+    // which is what the reference's box routine does for it.
+    __device__ __forceinline__ bool qboxTest(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t rx, uint32_t ry, uint32_t rz,
+        const RayState& r, float& entry) const
+    {
+        const uint32_t qx = __builtin_rotateleft32(wx, rx), qy = __builtin_rotateleft32(wy, ry), qz = __builtin_rotateleft32(wz, rz);
+        const float nx = __builtin_fmaf((float)(qx & 0xffffu), r.A.x, r.Bn.x), fx = __builtin_fmaf((float)(qx >> 16), r.A.x, r.Bf.x);
+        const float ny = __builtin_fmaf((float)(qy & 0xffffu), r.A.y, r.Bn.y), fy = __builtin_fmaf((float)(qy >> 16), r.A.y, r.Bf.y);
+        const float nz = __builtin_fmaf((float)(qz & 0xffffu), r.A.z, r.Bn.z), fz = __builtin_fmaf((float)(qz >> 16), r.A.z, r.Bf.z);
+        const float tIn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+        const float tOut = fminf(fminf(fx, fy), fz);
+        entry = tIn;
+        return tIn <= tOut && tIn <= r.tmax;
     }
 
     // Shared while-while traversal.  `minActive`: leave as soon as fewer lanes
@@ -106,19 +143,24 @@ struct Tracer {
     // Inner nodes until a leaf is reached, then that leaf.
     __device__ __forceinline__ void step(RayState& r) const
     {
-        // ---- inner nodes: one 64-B sibling-pair record per visit
+        // ---- inner nodes: one 32-B sibling-pair record per visit
+        const uint32_t rx = r.rot & 31u, ry = (r.rot >> 5) & 31u, rz = (r.rot >> 10) & 31u;
         while (!(r.cur & kLeafFlag) && r.cur != kRefNone) {
-            const float4* p = sc.pairs + 4u * r.cur;
-            const float4 a = p[0], b = p[1], c = p[2];
-            const uint2 refs = *reinterpret_cast<const uint2*>(p + 3);
+            const uint4* p = sc.pairs + 2u * r.cur;
+            const uint4 w0 = p[0], w1 = p[1];
             if (STATS)
                 r.nInner++;
             float eL, eR;
-            const bool hL = boxTest({ a.x, a.y, a.z }, { a.w, b.x, b.y }, r.o, r.inv, r.tmax, eL);
-            const bool hR = boxTest({ b.z, b.w, c.x }, { c.y, c.z, c.w }, r.o, r.inv, r.tmax, eR);
+            const bool hL = qboxTest(w0.x, w0.y, w0.z, rx, ry, rz, r, eL);
+            const bool hR = qboxTest(w0.w, w1.x, w1.y, rx, ry, rz, r, eR);
+            const uint2 refs = { w1.z, w1.w };
             if (hL && hR) {
                 // nearer child first; on a tie the right child, as in src/bvh.cpp:301-307
+#ifdef RT_SHADOW_FAR_FIRST
+                const bool leftFirst = (eL < eR) != (r.kind == K_SHADOW_ANY);
+#else
                 const bool leftFirst = eL < eR;
+#endif
                 push(r, leftFirst ? refs.y : refs.x);
                 r.cur = leftFirst ? refs.x : refs.y;
             } else if (hL) {
@@ -135,11 +177,15 @@ struct Tracer {
             const uint32_t cnt = (r.cur >> 27) & 15u;
             bool done = false;
             for (uint32_t i = 0; i < cnt; i++) {
-                const TriRec tr = loadTri(sc.tris, off + i);
                 float t;
                 if (STATS)
                     r.nTris++;
+#ifdef RT_TRI_EAGER
+                const TriRec tr = loadTri(sc.tris, off + i);
                 if (triangleTest(tr, r.o, r.d, r.tmax, t)) {
+#else
+                if (triangleTestLazy(sc.tris, off + i, r.o, r.d, r.tmax, t)) {
+#endif
                     r.tmax = t;
                     r.hitPrim = (int)(off + i);
                     // Binary visibility only asks whether the closest hit lies more

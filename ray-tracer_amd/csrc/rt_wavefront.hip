@@ -49,6 +49,8 @@ struct WfBuffers {
     float4* nodeA;       // [nodes*4] P.xyz N.x | N.yz rd.xy | rd.z kd.xyz | ks.xyz shininess
     NodeB* nodeB;        // [nodes]
     float* contrib;      // [nodes * slots * 3]
+    float4* srays;       // [nodes * slots * 3] shadow ray: origin.xyz length | direction.xyz 0 | light colour.xyz 0
+    uint8_t* svis;       // [nodes * slots]     1 = light sample visible
     uint32_t maxNodes;
 };
 
@@ -282,100 +284,112 @@ __global__ void prefixKernel(const DevFrame fr, const WfParams wp, const WfBuffe
 }
 
 // ---------------------------------------------------------------------------
-// 3. one light sample of one hit: computeContributionPointLight, src/light.cpp:166-186
+// 3. one light sample of one hit: computeContributionPointLight, src/light.cpp:166-186,
+//    in three kernels so that the divergent part (the traversal) carries nothing
+//    but the ray: (a) sample the light and build the shadow ray, one lane per
+//    (hit, sample), fully coherent; (b) any-hit traversal, persistent wavefronts
+//    pulling batches of rays from an atomic queue (every ray ends on a surface,
+//    so every ray enters the scene's box: nothing to compact away);
+//    (c) shade the visible samples, one lane per (hit, sample) again.
 // ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp,
+    const WfBuffers wb, DevCounters* __restrict__ ctr)
+{
+    const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
+    const uint32_t total = nNodes * wp.slots; // host guarantees maxNodes * slots < 2^32
+    for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
+        const uint32_t item = base + threadIdx.x;
+        if (item < total) {
+            const uint32_t node = item / wp.slots;
+            uint32_t slot = item % wp.slots;
+            // which light and which of its samples; draws consumed by the lights before it
+            int l = 0;
+            uint32_t drawPrefix = 0, perSample = 0;
+            for (; l < sc.nLights; l++) {
+                const int type = sc.lights[l].type;
+                const uint32_t n = (type == 0) ? 1u : ft.shadowSamples;
+                perSample = (type == 0) ? 0u : (type == 1 ? 1u : 2u);
+                if (slot < n)
+                    break;
+                slot -= n;
+                drawPrefix += n * perSample;
+            }
+            const NodeB nb = wb.nodeB[node];
+            const float4 a0 = wb.nodeA[4u * (size_t)node];
+            const f3 P = { a0.x, a0.y, a0.z };
+            int px, py;
+            slotToPixel(fr, wp.slotBegin + nb.path / wp.R, px, py);
+            const uint32_t seed = (uint32_t)(fr.height * px + py);
+            const uint32_t hitOrdinal = wb.pathBase[nb.path] + (uint32_t)nb.depth;
+            uint32_t s = lcgSkip(seed, wp.mainStart + wp.drawsPerHit * hitOrdinal + drawPrefix + slot * perSample);
+            const rt_light& light = sc.lights[l];
+            f3 pos, col;
+            if (light.type == 0) {
+                pos = ld3(light.v + 0);
+                col = ld3(light.v + 3);
+            } else if (light.type == 1) {
+                sampleSegmentLight(next1d(s), light, pos, col);
+            } else {
+                const float sx = next1d(s);
+                const float sy = next1d(s);
+                sampleParallelogramLight({ sx, sy }, light, pos, col);
+            }
+            f3 d;
+            float len = 0.0f;
+            if (ft.shadows) { // src/light.cpp:94-97: from the light to the hit point
+                const f3 toHit = P - pos;
+                d = normalize(toHit);
+                len = length(toHit);
+            } else { // src/light.cpp:270-272: no ray; keep minus the direction to the light
+                d = -normalize(pos - P);
+            }
+            float4* sr = wb.srays + 3u * (size_t)item;
+            sr[0] = make_float4(pos.x, pos.y, pos.z, len);
+            sr[1] = make_float4(d.x, d.y, d.z, 0.0f);
+            sr[2] = make_float4(col.x, col.y, col.z, 0.0f);
+            wb.svis[item] = 1; // visible unless the traversal finds an occluder
+        }
+    }
+}
+
 template <bool STATS>
-__global__ __launch_bounds__(256) void shadowKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp,
-    const WfBuffers wb, DevCounters* __restrict__ ctr, int minActive)
+__global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+    DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
     const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x, blockDim.x };
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
-    const uint32_t total = nNodes * wp.slots; // host guarantees maxNodes * slots < 2^32
+    const uint32_t nNodesAll = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
+    const uint32_t total = ft.shadows ? nNodesAll * wp.slots : 0u; // shadows off: no ray at all (src/light.cpp:270-272)
 
     RayState r;
     r.active = false;
     r.cur = kRefNone;
     r.sp = 0;
     r.nInner = r.nTris = 0;
-    uint32_t item = 0, nrays = 0;
-    f3 lcol = { 0.0f, 0.0f, 0.0f };
+    uint32_t item = 0;
     bool have = false, dead = false;
     WaveQueue q;
 
     for (;;) {
-        for (int round = 0; round < 2; round++) {
-            bool want = !have && !dead;
-            q.fetch(want, item, dead, &ctr->nextShadow, total, wp.chunk, lane);
-            if (!have && !dead && !want) {
-                const uint32_t node = item / wp.slots;
-                uint32_t slot = item % wp.slots;
-                // which light and which of its samples; draws consumed by the lights before it
-                int l = 0;
-                uint32_t drawPrefix = 0, perSample = 0;
-                for (; l < sc.nLights; l++) {
-                    const int type = sc.lights[l].type;
-                    const uint32_t n = (type == 0) ? 1u : ft.shadowSamples;
-                    perSample = (type == 0) ? 0u : (type == 1 ? 1u : 2u);
-                    if (slot < n)
-                        break;
-                    slot -= n;
-                    drawPrefix += n * perSample;
-                }
-                const NodeB nb = wb.nodeB[node];
-                const float4 a0 = wb.nodeA[4u * (size_t)node];
-                const f3 P = { a0.x, a0.y, a0.z };
-                int px, py;
-                slotToPixel(fr, wp.slotBegin + nb.path / wp.R, px, py);
-                const uint32_t seed = (uint32_t)(fr.height * px + py);
-                const uint32_t hitOrdinal = wb.pathBase[nb.path] + (uint32_t)nb.depth;
-                uint32_t s = lcgSkip(seed, wp.mainStart + wp.drawsPerHit * hitOrdinal + drawPrefix + slot * perSample);
-                const rt_light& light = sc.lights[l];
-                f3 pos, col;
-                if (light.type == 0) {
-                    pos = ld3(light.v + 0);
-                    col = ld3(light.v + 3);
-                } else if (light.type == 1) {
-                    sampleSegmentLight(next1d(s), light, pos, col);
-                } else {
-                    const float sx = next1d(s);
-                    const float sy = next1d(s);
-                    sampleParallelogramLight({ sx, sy }, light, pos, col);
-                }
-                lcol = col;
-                have = true;
-                if (ft.shadows) { // src/light.cpp:94-97
-                    const f3 toHit = P - pos;
-                    tracer.launch(r, pos, normalize(toHit), length(toHit), K_SHADOW_ANY);
-                    nrays++;
-                } else { // src/light.cpp:270-272: no ray; keep the direction to the light in r.d
-                    r.active = false;
-                    r.hitPrim = kHitNone;
-                    r.d = -normalize(pos - P);
-                }
-            }
-            if (have && !r.active) {
-                if (ft.shadows && sc.nSpheres)
-                    tracer.spheres(r);
-                const bool visible = (r.hitPrim == kHitNone) ? true : (fabsf(r.tmax - r.slen) <= 0.0001f); // src/light.cpp:101-107
-                f3 c = { 0.0f, 0.0f, 0.0f };
-                const f3 vis = visible ? lcol : mk3(0.0f);
-                if (!isZero(vis)) { // src/light.cpp:171-186
-                    const uint32_t node = item / wp.slots;
-                    const float4* a = wb.nodeA + 4u * (size_t)node;
-                    const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-                    const f3 N = { a0.w, a1.x, a1.y }, rd = { a1.z, a1.w, a2.x }, kd = { a2.y, a2.z, a2.w }, ks = { a3.x, a3.y, a3.z };
-                    c = computeShading(ft, N, kd, ks, a3.w, -rd, -r.d, vis);
-                }
-                float* dst = wb.contrib + 3u * (size_t)item;
-                dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
-                have = false;
-            }
-            if (__ballot(!have && !dead) == 0ull)
-                break;
+        bool want = !have && !dead;
+        q.fetch(want, item, dead, &ctr->nextShadow, total, wp.chunk, lane);
+        if (!have && !dead && !want) {
+            const float4* sr = wb.srays + 3u * (size_t)item;
+            const float4 a = sr[0], b = sr[1];
+            tracer.launch(r, { a.x, a.y, a.z }, { b.x, b.y, b.z }, a.w, K_SHADOW_ANY);
+            have = true;
         }
-        if (__ballot(r.active && have) == 0ull) {
+        if (have && !r.active) {
+            if (sc.nSpheres)
+                tracer.spheres(r);
+            // src/light.cpp:101-107
+            const bool visible = (r.hitPrim == kHitNone) ? true : (fabsf(r.tmax - r.slen) <= 0.0001f);
+            if (!visible)
+                wb.svis[item] = 0;
+            have = false;
+        }
+        if (__ballot(have) == 0ull) {
             if (__ballot(!dead) == 0ull)
                 break;
             continue;
@@ -383,13 +397,43 @@ __global__ __launch_bounds__(256) void shadowKernel(const DevScene sc, const Dev
         tracer.run(r, q.exhausted ? 0 : minActive);
     }
 
-    const unsigned long long rs = waveSum(nrays), ni = waveSum(r.nInner), nt = waveSum(r.nTris);
+    const unsigned long long ni = waveSum(r.nInner), nt = waveSum(r.nTris);
     if (lane == 0) {
-        atomicAdd(&ctr->rays, rs);
         if (STATS) {
             atomicAdd(&ctr->inner, ni);
             atomicAdd(&ctr->tris, nt);
+            atomicAdd(&ctr->sInner, ni);
+            atomicAdd(&ctr->sTris, nt);
         }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && ft.shadows) { // every (hit, sample) is one intersect call
+            const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
+            const unsigned long long n = (unsigned long long)nNodes * wp.slots;
+            atomicAdd(&ctr->rays, n);
+            atomicAdd(&ctr->sRays, n);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void shadowShadeKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+    const DevCounters* __restrict__ ctr)
+{
+    const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
+    const uint32_t total = nNodes * wp.slots;
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+        f3 c = { 0.0f, 0.0f, 0.0f };
+        const float4* sr = wb.srays + 3u * (size_t)item;
+        const float4 col = sr[2];
+        const f3 vis = wb.svis[item] ? mk3(col.x, col.y, col.z) : mk3(0.0f);
+        if (!isZero(vis)) { // src/light.cpp:171-186
+            const float4 d = sr[1];
+            const uint32_t node = item / wp.slots;
+            const float4* a = wb.nodeA + 4u * (size_t)node;
+            const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+            const f3 N = { a0.w, a1.x, a1.y }, rd = { a1.z, a1.w, a2.x }, kd = { a2.y, a2.z, a2.w }, ks = { a3.x, a3.y, a3.z };
+            c = computeShading(ft, N, kd, ks, a3.w, -rd, -mk3(d.x, d.y, d.z), vis);
+        }
+        float* dst = wb.contrib + 3u * (size_t)item;
+        dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
     }
 }
 
@@ -473,7 +517,7 @@ __global__ void combineKernel(const DevScene sc, const DevFeat ft, const DevFram
 // ---------------------------------------------------------------------------
 typedef void (*PathFn)(const DevScene, const DevCamera, const DevFeat, const DevFrame, const WfParams, const WfBuffers,
     DevCounters*, int);
-typedef void (*ShadowFn)(const DevScene, const DevFeat, const DevFrame, const WfParams, const WfBuffers, DevCounters*, int);
+typedef void (*ShadowFn)(const DevScene, const DevFeat, const WfParams, const WfBuffers, DevCounters*, int);
 
 static PathFn pathVariant(bool dof, bool stats)
 {
@@ -481,7 +525,7 @@ static PathFn pathVariant(bool dof, bool stats)
         return stats ? pathKernel<true, true> : pathKernel<true, false>;
     return stats ? pathKernel<false, true> : pathKernel<false, false>;
 }
-static ShadowFn shadowVariant(bool stats) { return stats ? shadowKernel<true> : shadowKernel<false>; }
+static ShadowFn shadowVariant(bool stats) { return stats ? shadowTraceKernel<true> : shadowTraceKernel<false>; }
 
 hipError_t wavefrontOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks)
 {
@@ -493,14 +537,22 @@ hipError_t wavefrontOccupancy(bool dof, bool stats, int blockThreads, size_t lds
 
 hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
-    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive)
+    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, hipEvent_t* marks, int numCU)
 {
+    // marks (optional, 3 events): after the path kernel, before and after the shadow-ray traversal
     hipLaunchKernelGGL(pathVariant(dof, stats), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, cam, ft, fr, wp, wb,
         ctr, minActive);
+    if (marks)
+        (void)hipEventRecord(marks[0], stream);
     const int pb = (int)((wp.nSlots + 255) / 256);
     hipLaunchKernelGGL(prefixKernel, dim3(pb), dim3(256), 0, stream, fr, wp, wb);
-    hipLaunchKernelGGL(shadowVariant(stats), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, fr, wp, wb, ctr,
-        minActive);
+    hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr);
+    if (marks)
+        (void)hipEventRecord(marks[1], stream);
+    hipLaunchKernelGGL(shadowVariant(stats), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActive);
+    if (marks)
+        (void)hipEventRecord(marks[2], stream);
+    hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
     hipLaunchKernelGGL(combineKernel, dim3(pb), dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
     return hipGetLastError();
 }
