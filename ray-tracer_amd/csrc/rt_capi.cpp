@@ -55,7 +55,7 @@ struct WfParams {
 hipError_t wavefrontOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
 hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
-    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, hipEvent_t* marks, int numCU);
+    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
 } // namespace rt
 
 using namespace rt;
@@ -93,7 +93,8 @@ struct rt_ctx {
     rt_features features {};
     bool haveFeatures = false;
     // tuning knobs of the render kernel (environment-overridable for experiments)
-    int minActive = 32;
+    int minActive = 32;       // per-pixel and path kernels: leave the traversal loop below this many rays in flight
+    int minActiveShadow = 48; // shadow-ray kernel (its refill is cheap)
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
     int forcePerPixel = 0; // 1 = always use the per-pixel kernel
@@ -163,7 +164,9 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         return fail(nullptr, RT_ERR_DEVICE, "rt_ctx_create: device allocation failed");
     }
     if (const char* s = getenv("RT_AMD_MIN_ACTIVE"))
-        ctx->minActive = atoi(s);
+        ctx->minActive = ctx->minActiveShadow = atoi(s);
+    if (const char* s = getenv("RT_AMD_MIN_ACTIVE_SHADOW"))
+        ctx->minActiveShadow = atoi(s);
     if (const char* s = getenv("RT_AMD_LOGIC_ROUNDS"))
         ctx->logicRounds = std::max(1, atoi(s));
     if (const char* s = getenv("RT_AMD_BLOCKS_PER_CU"))
@@ -803,7 +806,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                 ctx->evHasMarks[ctx->evUsed / 5] = 1;
             }
             HIP_TRY(ctx, launchWavefront(dof, collect, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
-                              wb, ctx->dCounters, dOut, ctx->minActive, marks, ctx->numCU));
+                              wb, ctx->dCounters, dOut, ctx->minActive, ctx->minActiveShadow, marks, ctx->numCU));
         }
     }
     if (timeIt) {

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
     Frame frames[kMaxDepth + 1];
     GlossyFrame gframes[(V & V_GLOSSY) ? (kMaxDepth + 1) : 1];
 
-    const Tracer<(V & V_STATS) != 0> tracer { sc, ft.accel, stackMem + threadIdx.x, blockDim.x };
+    const Tracer<(V & V_STATS) != 0> tracer { sc, ft.accel, stackMem + threadIdx.x };
     const Shader<V> shader { sc, cam, ft, fr, tracer, out, frames, gframes };
 
     Lane L;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void intersectKernel(const DevScene sc, const 
     rt_hit* __restrict__ hits, uint32_t n)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<false> tracer { sc, ft.accel, stackMem + threadIdx.x, blockDim.x };
+    const Tracer<false> tracer { sc, ft.accel, stackMem + threadIdx.x };
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     RayState L;
     L.cur = kRefNone;

@@ -9,6 +9,8 @@
 
 namespace rt {
 
+constexpr uint32_t kBlockThreads = 256;
+
 enum RayKind : int { K_RADIANCE = 0, K_SHADOW_ANY = 1, K_SHADOW_CLOSEST = 2 };
 
 constexpr int kHitNone = -1;
@@ -27,6 +29,7 @@ struct RayState {
     int hitPrim;      // primitive index, kHitNone, or -2 - sphere index
     int kind;
     uint32_t cur;     // node reference being visited, kRefNone when finished
+    uint32_t li, le;  // inside a leaf: next primitive and end of the leaf
     int sp;
     bool active;      // still inside the traversal loop
     uint32_t nInner, nTris;
@@ -42,7 +45,7 @@ struct Tracer {
     const DevScene& sc;
     int accel;
     uint32_t* stk; // this lane's column of the LDS stack
-    uint32_t stride;
+    static constexpr uint32_t stride = kBlockThreads; // every traversing kernel runs 256-thread blocks
 
     __device__ __forceinline__ uint32_t pop(RayState& r) const
     {
@@ -76,8 +79,8 @@ struct Tracer {
             float e;
             const f3 lo = { sc.rootLo[0], sc.rootLo[1], sc.rootLo[2] }, hi = { sc.rootHi[0], sc.rootHi[1], sc.rootHi[2] };
             if (sc.nPrims != 0 && boxTest(lo, hi, o, inv, kFltMax, e)) {
-                r.cur = sc.rootRef;
                 r.active = true;
+                setCur(r, sc.rootRef);
                 // t(q) = ((gridMin + q*cell) - o) * inv = q*A + B.  Rounding bound of the
                 // fused form: (|q*A| + |B|) * 2^-22 for the inputs plus half an ulp of
                 // the result; (extent*|inv| + |B|) * 2^-20 covers it with room to spare.
@@ -125,82 +128,95 @@ struct Tracer {
         return tIn <= tOut && tIn <= r.tmax;
     }
 
-    // Shared while-while traversal.  `minActive`: leave as soon as fewer lanes
-    // than this still have a ray in flight (0 = run every ray to completion).
-    __device__ __forceinline__ void run(RayState& r, int minActive) const
+    // Make `ref` the node being visited; a leaf gets its primitive cursor.
+    __device__ __forceinline__ void setCur(RayState& r, uint32_t ref) const
     {
-        if (__ballot(r.active) == 0ull)
-            return;
-        for (;;) {
-            if (r.active)
-                step(r);
-            const int n = __popcll(__ballot(r.active));
-            if (n == 0 || n < minActive)
-                break;
+        r.cur = ref;
+        if (ref == kRefNone) {
+            r.active = false;
+        } else if (ref & kLeafFlag) {
+            r.li = ref & kLeafOffsetMask;
+            r.le = r.li + ((ref >> 27) & 15u);
         }
     }
 
-    // Inner nodes until a leaf is reached, then that leaf.
-    __device__ __forceinline__ void step(RayState& r) const
+    // Shared traversal loop.  Every lane with a ray in flight is either at an
+    // inner node or inside a leaf; per iteration the wave runs ONE of the two
+    // code blocks, whichever more lanes are waiting for (ballot vote), so no
+    // lane ever idles behind a long run of the other kind and an iteration is
+    // never spent on a block that only a few lanes want.  An inner iteration
+    // visits one sibling pair, a leaf iteration tests one primitive; the order
+    // of the tests along one ray is unchanged (near child first, the
+    // primitives of a leaf in order), only the interleaving between lanes is.
+    // `minActive`: leave as soon as fewer lanes than this still have a ray in
+    // flight (0 = run every ray to completion).
+    __device__ __forceinline__ void run(RayState& r, int minActive) const
     {
-        // ---- inner nodes: one 32-B sibling-pair record per visit
         const uint32_t rx = r.rot & 31u, ry = (r.rot >> 5) & 31u, rz = (r.rot >> 10) & 31u;
-        while (!(r.cur & kLeafFlag) && r.cur != kRefNone) {
-            const uint4* p = sc.pairs + 2u * r.cur;
-            const uint4 w0 = p[0], w1 = p[1];
-            if (STATS)
-                r.nInner++;
-            float eL, eR;
-            const bool hL = qboxTest(w0.x, w0.y, w0.z, rx, ry, rz, r, eL);
-            const bool hR = qboxTest(w0.w, w1.x, w1.y, rx, ry, rz, r, eR);
-            const uint2 refs = { w1.z, w1.w };
-            if (hL && hR) {
-                // nearer child first; on a tie the right child, as in src/bvh.cpp:301-307
-#ifdef RT_SHADOW_FAR_FIRST
-                const bool leftFirst = (eL < eR) != (r.kind == K_SHADOW_ANY);
-#else
-                const bool leftFirst = eL < eR;
-#endif
-                push(r, leftFirst ? refs.y : refs.x);
-                r.cur = leftFirst ? refs.x : refs.y;
-            } else if (hL) {
-                r.cur = refs.x;
-            } else if (hR) {
-                r.cur = refs.y;
-            } else {
-                r.cur = pop(r);
+        for (;;) {
+            const bool atLeaf = r.active && (r.cur & kLeafFlag);
+            const bool atInner = r.active && !(r.cur & kLeafFlag);
+            const int nLeaf = __popcll(__ballot(atLeaf)), nInner = __popcll(__ballot(atInner));
+            if (nLeaf + nInner == 0 || nLeaf + nInner < minActive)
+                break;
+            if (nInner >= nLeaf) {
+                if (atInner)
+                    innerStep(r, rx, ry, rz);
+            } else if (atLeaf) {
+                leafStep(r);
             }
         }
-        // ---- leaf: every primitive of the leaf, in order (src/bvh.cpp:272-279)
-        if (r.cur != kRefNone) {
-            const uint32_t off = r.cur & kLeafOffsetMask;
-            const uint32_t cnt = (r.cur >> 27) & 15u;
-            bool done = false;
-            for (uint32_t i = 0; i < cnt; i++) {
-                float t;
-                if (STATS)
-                    r.nTris++;
-#ifdef RT_TRI_EAGER
-                const TriRec tr = loadTri(sc.tris, off + i);
-                if (triangleTest(tr, r.o, r.d, r.tmax, t)) {
-#else
-                if (triangleTestLazy(sc.tris, off + i, r.o, r.d, r.tmax, t)) {
-#endif
-                    r.tmax = t;
-                    r.hitPrim = (int)(off + i);
-                    // Binary visibility only asks whether the closest hit lies more
-                    // than 1e-4 before the target (src/light.cpp:101-104); any hit
-                    // that does settles it, the closest one is at least as near.
-                    if (r.kind == K_SHADOW_ANY && fabsf(t - r.slen) > 0.0001f) {
-                        done = true;
-                        break;
-                    }
+    }
+
+    // One sibling-pair record (32 B): test both children, descend into the nearer.
+    __device__ __forceinline__ void innerStep(RayState& r, uint32_t rx, uint32_t ry, uint32_t rz) const
+    {
+        const uint4* p = sc.pairs + 2u * r.cur;
+        const uint4 w0 = p[0], w1 = p[1];
+        if (STATS)
+            r.nInner++;
+        float eL, eR;
+        const bool hL = qboxTest(w0.x, w0.y, w0.z, rx, ry, rz, r, eL);
+        const bool hR = qboxTest(w0.w, w1.x, w1.y, rx, ry, rz, r, eR);
+        uint32_t next;
+        if (hL && hR) {
+            // nearer child first; on a tie the right child, as in src/bvh.cpp:301-307
+            const bool leftFirst = eL < eR;
+            push(r, leftFirst ? w1.w : w1.z);
+            next = leftFirst ? w1.z : w1.w;
+        } else if (hL) {
+            next = w1.z;
+        } else if (hR) {
+            next = w1.w;
+        } else {
+            next = pop(r);
+        }
+        setCur(r, next);
+    }
+
+    // One primitive of the current leaf, in order (src/bvh.cpp:272-279).
+    __device__ __forceinline__ void leafStep(RayState& r) const
+    {
+        if (r.li < r.le) {
+            float t;
+            if (STATS)
+                r.nTris++;
+            if (triangleTestLazy(sc.tris, r.li, r.o, r.d, r.tmax, t)) {
+                r.tmax = t;
+                r.hitPrim = (int)r.li;
+                // Binary visibility only asks whether the closest hit lies more
+                // than 1e-4 before the target (src/light.cpp:101-104); any hit
+                // that does settles it, the closest one is at least as near.
+                if (r.kind == K_SHADOW_ANY && fabsf(t - r.slen) > 0.0001f) {
+                    r.cur = kRefNone;
+                    r.active = false;
+                    return;
                 }
             }
-            r.cur = done ? kRefNone : pop(r);
+            r.li++;
         }
-        if (r.cur == kRefNone)
-            r.active = false;
+        if (r.li >= r.le)
+            setCur(r, pop(r));
     }
 
     // Spheres are tested after the BVH, in order, against the current ray.t

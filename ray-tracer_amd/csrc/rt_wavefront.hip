@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevCa
     const WfParams wp, const WfBuffers wb, DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x, blockDim.x };
+    const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x };
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = wp.nSlots * wp.R;
 
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x, blockDim.x };
+    const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x };
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nNodesAll = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
     const uint32_t total = ft.shadows ? nNodesAll * wp.slots : 0u; // shadows off: no ray at all (src/light.cpp:270-272)
@@ -537,7 +537,7 @@ hipError_t wavefrontOccupancy(bool dof, bool stats, int blockThreads, size_t lds
 
 hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
-    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, hipEvent_t* marks, int numCU)
+    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU)
 {
     // marks (optional, 3 events): after the path kernel, before and after the shadow-ray traversal
     hipLaunchKernelGGL(pathVariant(dof, stats), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, cam, ft, fr, wp, wb,
@@ -549,7 +549,7 @@ hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlock
     hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr);
     if (marks)
         (void)hipEventRecord(marks[1], stream);
-    hipLaunchKernelGGL(shadowVariant(stats), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActive);
+    hipLaunchKernelGGL(shadowVariant(stats), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
     if (marks)
         (void)hipEventRecord(marks[2], stream);
     hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
