@@ -1,5 +1,6 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -275,3 +276,14 @@ def test_empty_scene_and_spheres(ctx):
     img, st_g = ctx.render(cam, 64, 64)
     assert st_g["rays"] == st_o["rays"] and ref.any()
     assert common.image_error(img, ref)[0] <= 2e-5
+
+
+def test_cpp_host_mirror():
+    """The C++ host API (rt_host.hpp: Scene / BVH / Trackball / renderImage with the
+    reference's names) against the reference's pyramid test and the oracle."""
+    import subprocess
+    exe = os.path.join(common.ROOT, "ray-tracer_amd", "host", "host_tests")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(out.stdout[-600:])
+    assert out.returncode == 0, out.stdout + out.stderr
