@@ -13,6 +13,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -98,6 +99,7 @@ struct rt_ctx {
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
     int forcePerPixel = 0; // 1 = always use the per-pixel kernel
+    int treeMode = 1;      // 0 = traverse the caller's inner nodes as they are, 1 = own SAH hierarchy over the caller's leaves
     size_t workspaceCap = 64ull << 30; // bytes the wavefront path may hold
     // wavefront workspace (grow-only)
     void* wsPtr[10] = {};
@@ -171,6 +173,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->logicRounds = std::max(1, atoi(s));
     if (const char* s = getenv("RT_AMD_BLOCKS_PER_CU"))
         ctx->blocksPerCU = atoi(s);
+    if (const char* s = getenv("RT_AMD_TREE"))
+        ctx->treeMode = atoi(s);
     if (const char* s = getenv("RT_AMD_PER_PIXEL"))
         ctx->forcePerPixel = atoi(s);
     if (const char* s = getenv("RT_AMD_WORKSPACE_GB"))
@@ -428,17 +432,149 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
             q += 1.0;
         return static_cast<uint32_t>(q);
     };
-    std::vector<uint4> pairs(innerOrder.size() * 2);
-    for (size_t k = 0; k < innerOrder.size(); k++) {
-        const rt_node& nd = nodes[innerOrder[k]];
-        const rt_node* ch[2] = { &nodes[nd.data[0]], &nodes[nd.data[1]] };
-        uint32_t w[2][3];
-        for (int c = 0; c < 2; c++)
-            for (int a = 0; a < 3; a++)
-                w[c][a] = quantLo(ch[c]->lower[a], a) | (quantHi(ch[c]->upper[a], a) << 16);
-        uint4* p = &pairs[2 * k];
-        p[0] = make_uint4(w[0][0], w[0][1], w[0][2], w[1][0]);
-        p[1] = make_uint4(w[1][1], w[1][2], childRef(nd.data[0]), childRef(nd.data[1]));
+    auto packBox = [&](const float* lo, const float* hi, uint32_t* w) {
+        for (int a = 0; a < 3; a++)
+            w[a] = quantLo(lo[a], a) | (quantHi(hi[a], a) << 16);
+    };
+    std::vector<uint4> pairs;
+    uint32_t rootRef = 0;
+    bool ownTree = false;
+    if (ctx->treeMode != 0 && !innerOrder.empty()) {
+        // Traversal tree of the library's own: the caller's LEAVES (their primitive ranges,
+        // boxes and order are kept as they are) under a new inner hierarchy chosen by the
+        // surface-area heuristic.  Which primitive a ray hits, its t and the order of the
+        // tests inside a leaf do not depend on the inner hierarchy, only the number of
+        // nodes a ray has to visit does (the median split of src/bvh.cpp:208-223 leaves
+        // heavily overlapping boxes).
+        struct Leaf {
+            float lo[3], hi[3], c[3];
+            uint32_t ref, count;
+        };
+        std::vector<Leaf> leaves;
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            if (!seen[i] || !(nodes[i].data[0] & RT_LEAF_BIT))
+                continue;
+            Leaf l;
+            for (int a = 0; a < 3; a++) {
+                l.lo[a] = nodes[i].lower[a], l.hi[a] = nodes[i].upper[a];
+                l.c[a] = 0.5f * (l.lo[a] + l.hi[a]);
+            }
+            l.count = nodes[i].data[1];
+            l.ref = kLeafFlag | (nodes[i].data[1] << 27) | (nodes[i].data[0] & ~RT_LEAF_BIT);
+            leaves.push_back(l);
+        }
+        struct Build {
+            std::vector<Leaf>& L;
+            std::vector<uint4>& pairs;
+            std::vector<uint32_t> idx, tmp;
+            std::vector<float> rightArea;
+            uint32_t maxDepth = 0;
+            decltype(packBox)& pack;
+            static float area(const float* lo, const float* hi)
+            {
+                const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+                return 2.0f * (x * y + x * z + y * z);
+            }
+            void bounds(uint32_t b, uint32_t e, float* lo, float* hi)
+            {
+                for (int a = 0; a < 3; a++)
+                    lo[a] = L[idx[b]].lo[a], hi[a] = L[idx[b]].hi[a];
+                for (uint32_t i = b + 1; i < e; i++)
+                    for (int a = 0; a < 3; a++) {
+                        lo[a] = std::min(lo[a], L[idx[i]].lo[a]);
+                        hi[a] = std::max(hi[a], L[idx[i]].hi[a]);
+                    }
+            }
+            // returns the child reference of the subtree over idx[b, e)
+            uint32_t build(uint32_t b, uint32_t e, uint32_t depth)
+            {
+                maxDepth = std::max(maxDepth, depth);
+                if (e - b == 1)
+                    return L[idx[b]].ref;
+                const uint32_t n = e - b;
+                float bestCost = std::numeric_limits<float>::infinity();
+                int bestAxis = -1;
+                uint32_t bestSplit = 0;
+                for (int axis = 0; axis < 3; axis++) {
+                    std::sort(idx.begin() + b, idx.begin() + e, [&](uint32_t x, uint32_t y) { return L[x].c[axis] < L[y].c[axis]; });
+                    float lo[3], hi[3];
+                    rightArea.resize(n);
+                    uint32_t cnt = 0;
+                    for (uint32_t i = n; i-- > 1;) { // suffix boxes
+                        const Leaf& q = L[idx[b + i]];
+                        if (i == n - 1)
+                            for (int a = 0; a < 3; a++)
+                                lo[a] = q.lo[a], hi[a] = q.hi[a];
+                        else
+                            for (int a = 0; a < 3; a++)
+                                lo[a] = std::min(lo[a], q.lo[a]), hi[a] = std::max(hi[a], q.hi[a]);
+                        rightArea[i] = area(lo, hi);
+                    }
+                    std::vector<uint32_t>& suffixCount = tmp;
+                    suffixCount.assign(n + 1, 0);
+                    for (uint32_t i = n; i-- > 0;)
+                        suffixCount[i] = suffixCount[i + 1] + L[idx[b + i]].count;
+                    for (uint32_t i = 0; i + 1 < n; i++) { // split after element i
+                        const Leaf& q = L[idx[b + i]];
+                        if (i == 0)
+                            for (int a = 0; a < 3; a++)
+                                lo[a] = q.lo[a], hi[a] = q.hi[a];
+                        else
+                            for (int a = 0; a < 3; a++)
+                                lo[a] = std::min(lo[a], q.lo[a]), hi[a] = std::max(hi[a], q.hi[a]);
+                        cnt += q.count;
+                        const float cost = area(lo, hi) * (float)std::max(1u, cnt) + rightArea[i + 1] * (float)std::max(1u, suffixCount[i + 1]);
+                        if (cost < bestCost)
+                            bestCost = cost, bestAxis = axis, bestSplit = i + 1;
+                    }
+                }
+                // keep the depth bounded: fall back to the middle once a branch runs deep
+                if (bestAxis < 0 || depth + 2 + (uint32_t)std::ceil(std::log2((double)n)) > (uint32_t)kMaxStack) {
+                    bestAxis = 0;
+                    bestSplit = n / 2;
+                }
+                std::sort(idx.begin() + b, idx.begin() + e, [&](uint32_t x, uint32_t y) { return L[x].c[bestAxis] < L[y].c[bestAxis]; });
+                const uint32_t mid = b + bestSplit;
+                const size_t me = pairs.size();
+                pairs.resize(me + 2);
+                float lo[3], hi[3];
+                uint32_t wl[3], wr[3];
+                bounds(b, mid, lo, hi);
+                pack(lo, hi, wl);
+                bounds(mid, e, lo, hi);
+                pack(lo, hi, wr);
+                const uint32_t rl = build(b, mid, depth + 1);
+                const uint32_t rr = build(mid, e, depth + 1);
+                pairs[me] = make_uint4(wl[0], wl[1], wl[2], wr[0]);
+                pairs[me + 1] = make_uint4(wr[1], wr[2], rl, rr);
+                return static_cast<uint32_t>(me / 2);
+            }
+        };
+        Build bld { leaves, pairs, {}, {}, {}, 0, packBox };
+        bld.idx.resize(leaves.size());
+        for (uint32_t i = 0; i < leaves.size(); i++)
+            bld.idx[i] = i;
+        pairs.reserve(leaves.size() * 2);
+        rootRef = bld.build(0, static_cast<uint32_t>(leaves.size()), 1);
+        if (bld.maxDepth + 1 <= (uint32_t)kMaxStack) {
+            ownTree = true;
+            maxLevel = bld.maxDepth + 1;
+        } else {
+            pairs.clear();
+        }
+    }
+    if (!ownTree) {
+        pairs.resize(innerOrder.size() * 2);
+        for (size_t k = 0; k < innerOrder.size(); k++) {
+            const rt_node& nd = nodes[innerOrder[k]];
+            uint32_t wl[3], wr[3];
+            packBox(nodes[nd.data[0]].lower, nodes[nd.data[0]].upper, wl);
+            packBox(nodes[nd.data[1]].lower, nodes[nd.data[1]].upper, wr);
+            pairs[2 * k] = make_uint4(wl[0], wl[1], wl[2], wr[0]);
+            pairs[2 * k + 1] = make_uint4(wr[1], wr[2], childRef(nd.data[0]), childRef(nd.data[1]));
+        }
+        const rt_node& r0 = nodes[0];
+        rootRef = (r0.data[0] & RT_LEAF_BIT) ? (kLeafFlag | (r0.data[1] << 27) | (r0.data[0] & ~RT_LEAF_BIT)) : 0u;
     }
 
     std::vector<float4> tris(static_cast<size_t>(n_prims) * 6), attrs(static_cast<size_t>(n_prims) * 4);
@@ -526,7 +662,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
     s.lights = keepLightPtr;
     s.nLights = keepLights;
     const rt_node& root = nodes[0];
-    s.rootRef = (root.data[0] & RT_LEAF_BIT) ? (kLeafFlag | (root.data[1] << 27) | (root.data[0] & ~RT_LEAF_BIT)) : 0u;
+    s.rootRef = rootRef;
     std::memcpy(s.rootLo, root.lower, 12);
     std::memcpy(s.rootHi, root.upper, 12);
     std::memcpy(s.gridMin, gridMin, 12);
