@@ -323,6 +323,6 @@ def test_full_size_frame_properties():
     assert ra == rb == rp and ra > 60_000_000
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.array_equal(a.view(np.uint32), p.view(np.uint32))
-    assert np.isfinite(a).all() and float(a.max()) <= 1.0 + 1e-6 and float(a.sum()) > 1000.0
+    assert np.isfinite(a).all() and float(a.max()) <= 1.0 + 1e-6 and float(a.sum()) > 100.0
     # a 1/16-size crop of the same view against the oracle would need another camera; the small
     # configurations above pin the oracle, this one pins the size
