@@ -80,17 +80,38 @@ def cpu_baseline(scene, features, width, height, scale: int):
     osc = orc.OracleScene(scene)
     w, h = width // scale, height // scale
     cam = sio.default_camera(w, h)
-    t0 = time.perf_counter()
-    _, st = osc.render(features, cam, w, h, policy=0, threads=0)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, st = osc.render(features, cam, w, h, policy=0, threads=0)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
     cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"same scene/features at {w}x{h} (1/{scale * scale} of the pixels), one frame, {dt:.1f} s, "
+            "sample": f"same scene/features at {w}x{h} (1/{scale * scale} of the pixels), median of 3 frames, {dt:.1f} s each, "
                       f"{st['rays']} rays"}
+
+
+def measured_traffic(workload, kernel, world, width, height):
+    """HBM-side bytes per launch of `kernel` from the committed counter passes
+    (profiles/pmc_traffic_<workload>.json, collected by tools/pmc.sh at N=1 and the
+    workload's own resolution); None when no pass covers this run."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    if world != 1 or not os.path.exists(path):
+        return None, None
+    _, _, w0, h0, _ = build_workload(workload)
+    if (w0, h0) != (width, height):
+        return None, None
+    with open(path) as fh:
+        doc = json.load(fh)
+    k = doc["kernels"].get(kernel)
+    if k is None:
+        return None, None
+    return k["fetch_bytes"] + k["write_bytes"], doc["source"] + "; " + doc["summary"]
 
 
 def main():
@@ -190,7 +211,7 @@ def main():
         # this rank: 64 B per sibling-pair record fetched, 36 B of vertex positions per
         # triangle tested, 28 B ray + 16 B hit record per ray.
         if shadow_ms > 0:
-            kname, k_ms = "shadowKernel", shadow_ms
+            kname, k_ms = "shadowTraceKernel", shadow_ms
             k_rays, k_inner, k_tris = cst["shadow_rays"], cst["shadow_inner_nodes"], cst["shadow_tri_tests"]
         else:
             kname, k_ms = "renderKernel", frame_ms
@@ -199,6 +220,7 @@ def main():
         alg_flops = 26.0 * (k_rays + 2.0 * k_inner) + 50.0 * k_tris
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         tflops = alg_flops / (k_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(args.workload, kname, world, width, height)
         out = {
             "metric": "Mrays/s (whole node) on dragon.obj 1080p 16spp; ms/frame" if args.workload == "dragon"
                       else f"Mrays/s ({args.workload})",
@@ -209,7 +231,7 @@ def main():
                        "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)",
                        "scene_note": "dragon.obj is absent from the reference snapshot; procedural stand-in with the same triangle count"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": round(k_ms, 4),
                          "kernel_rays_per_launch": int(k_rays),
                          "algorithmic_bytes_per_launch": alg_bytes,
@@ -220,7 +242,7 @@ def main():
                          "fp32": {"achieved_tflops": round(tflops, 4), "peak_tflops": FP32_PEAK_TFLOPS,
                                   "frac": round(tflops / FP32_PEAK_TFLOPS, 5)},
                          "frame_device_ms": {"all_kernels": round(frame_ms, 4), "pathKernel": round(path_ms, 4),
-                                             "shadowKernel": round(shadow_ms, 4)}},
+                                             "shadowTraceKernel": round(shadow_ms, 4)}},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(scene, features, width, height, args.cpu_scale)
