@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "rt_device.hpp"
+#include "rt_wavefront.hpp"
 
 namespace rt {
 hipError_t renderOccupancy(int variant, int blockThreads, size_t ldsBytes, int* blocksPerCU);
@@ -30,33 +31,6 @@ hipError_t launchDeinterleave(hipStream_t stream, const float* packed, float* fr
 hipError_t launchEval(hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, int kind,
     const float* in, float* out, uint32_t n);
 
-// mirrors of the structs in rt_wavefront.hip
-struct NodeB {
-    uint32_t path;
-    int32_t depth;
-    int32_t child;
-    float cv[3];
-    uint32_t pad[2];
-};
-struct WfBuffers {
-    int32_t* pathHead;
-    uint8_t* pathCount;
-    uint32_t* pathBase;
-    float* pathEnv;
-    float4* nodeA;
-    NodeB* nodeB;
-    float* contrib;
-    float4* srays;
-    uint8_t* svis;
-    uint32_t maxNodes;
-};
-struct WfParams {
-    uint32_t slotBegin, nSlots, R, slots, drawsPerHit, pixDraws, mainStart, chunk;
-};
-hipError_t wavefrontOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
-hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
-    hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
-    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
 } // namespace rt
 
 using namespace rt;
@@ -96,6 +70,9 @@ struct rt_ctx {
     // tuning knobs of the render kernel (environment-overridable for experiments)
     int minActive = 32;       // per-pixel and path kernels: leave the traversal loop below this many rays in flight
     int minActiveShadow = 48; // shadow-ray kernel (its refill is cheap)
+    // switch points of the traversal loop between inner steps and triangle tests (rt_trace.hpp):
+    // lanes blocked before triangles are tested; lanes still holding a leaf when inner steps resume
+    int parkA = 16, parkB = 32, parkAShadow = 16, parkBShadow = 32;
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
     int forcePerPixel = 0; // 1 = always use the per-pixel kernel
@@ -169,6 +146,14 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->minActive = ctx->minActiveShadow = atoi(s);
     if (const char* s = getenv("RT_AMD_MIN_ACTIVE_SHADOW"))
         ctx->minActiveShadow = atoi(s);
+    if (const char* s = getenv("RT_AMD_PARK_A"))
+        ctx->parkA = ctx->parkAShadow = atoi(s);
+    if (const char* s = getenv("RT_AMD_PARK_B"))
+        ctx->parkB = ctx->parkBShadow = atoi(s);
+    if (const char* s = getenv("RT_AMD_PARK_A_SHADOW"))
+        ctx->parkAShadow = atoi(s);
+    if (const char* s = getenv("RT_AMD_PARK_B_SHADOW"))
+        ctx->parkBShadow = atoi(s);
     if (const char* s = getenv("RT_AMD_LOGIC_ROUNDS"))
         ctx->logicRounds = std::max(1, atoi(s));
     if (const char* s = getenv("RT_AMD_BLOCKS_PER_CU"))
@@ -797,6 +782,12 @@ static size_t shardTiles(int width, int height, int shard, int nShard)
     return (tiles > static_cast<size_t>(shard)) ? (tiles - shard + nShard - 1) / nShard : 0;
 }
 
+static int traceKnobs(int minActive, int a, int b)
+{
+    auto c = [](int v) { return std::max(0, std::min(v, 255)); };
+    return c(minActive) | (c(a) << 8) | (c(b) << 16);
+}
+
 static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int height, int shard, int nShard, float* dOut,
     size_t dOutFloats, hipStream_t stream, bool collect, bool timeIt)
 {
@@ -865,7 +856,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         int blocks = std::min<int64_t>(static_cast<int64_t>(ctx->numCU) * perCU, (wavesNeeded + 3) / 4);
         blocks = std::max(blocks, 1);
         HIP_TRY(ctx, launchRender(variant, blocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, ctx->dCounters, dOut,
-                          ctx->minActive, ctx->logicRounds));
+                          traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB), ctx->logicRounds));
     } else {
         // ---- wavefront path: work items are camera rays and light samples
         WfParams wp {};
@@ -885,7 +876,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         if (wp.R == 0 || wp.R > 65535u)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
         const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * (F.enableReflections ? F.maxRayDepth + 1 : 1);
-        const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + (F.enableEnvironmentMap ? 12 : 0))
+        const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + 32 + (F.enableEnvironmentMap ? 12 : 0))
             + nodesPerPixel * (64 + sizeof(NodeB) + (12ull + 48 + 1) * std::max(1u, slots));
         uint64_t batchSlots = ctx->workspaceCap / std::max<uint64_t>(1, bytesPerPixel);
         batchSlots = std::min<uint64_t>(batchSlots, 0x7fffffffull / wp.R);                                       // path index in 31 bits
@@ -895,10 +886,10 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: one tile of this frame needs more than the %zu-byte workspace", ctx->workspaceCap);
         const uint64_t paths = batchSlots * wp.R, maxNodes = batchSlots * nodesPerPixel;
         const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, slots);
-        const size_t want[9] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
+        const size_t want[10] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
             F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
-            static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * 48, items };
-        for (int i = 0; i < 9; i++) {
+            static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * 48, items, static_cast<size_t>(paths) * 32 };
+        for (int i = 0; i < 10; i++) {
             if (ctx->wsBytes[i] < want[i]) {
                 HIP_TRY(ctx, hipStreamSynchronize(stream));
                 if (ctx->wsPtr[i])
@@ -919,12 +910,13 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         wb.contrib = static_cast<float*>(ctx->wsPtr[6]);
         wb.srays = static_cast<float4*>(ctx->wsPtr[7]);
         wb.svis = static_cast<uint8_t*>(ctx->wsPtr[8]);
+        wb.camRays = static_cast<float4*>(ctx->wsPtr[9]);
         wb.maxNodes = static_cast<uint32_t>(maxNodes);
 
         const bool dof = F.enableDepthOfField != 0;
         int pathPerCU = ctx->blocksPerCU, shadowPerCU = ctx->blocksPerCU;
         if (pathPerCU <= 0) {
-            HIP_TRY(ctx, wavefrontOccupancy(dof, collect, blockThreads, lds, &pathPerCU, &shadowPerCU));
+            HIP_TRY(ctx, wavefrontOccupancy(collect, blockThreads, lds, &pathPerCU, &shadowPerCU));
             pathPerCU = std::max(1, std::min(pathPerCU, 8));
             shadowPerCU = std::max(1, std::min(shadowPerCU, 8));
         }
@@ -933,8 +925,15 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             wp.nSlots = static_cast<uint32_t>(std::min<uint64_t>(batchSlots, fr.nWork - begin));
             if (begin != 0) // queue heads and the node allocator start over; the ray counters keep adding up
                 HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctx->dCounters) + offsetof(DevCounters, next), 0, 16, stream));
-            const uint64_t items = static_cast<uint64_t>(wp.nSlots) * wp.R;
-            const int pathBlocks = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->numCU) * pathPerCU, (items + 255) / 256)));
+            // real pixels of the batch's tiles (edge tiles are padded to 8x8 slots)
+            uint64_t validPixels = 0;
+            for (uint64_t t = begin / 64; t < (begin + wp.nSlots) / 64; t++) {
+                const uint64_t tile = t * static_cast<uint64_t>(nShard) + shard;
+                const int tx = static_cast<int>(tile % fr.tilesX), ty = static_cast<int>(tile / fr.tilesX);
+                validPixels += static_cast<uint64_t>(std::min(kTile, width - tx * kTile)) * std::min(kTile, height - ty * kTile);
+            }
+            wp.validPaths = static_cast<uint32_t>(validPixels * wp.R);
+            const int pathBlocks = ctx->numCU * pathPerCU;
             const int shadowBlocks = ctx->numCU * shadowPerCU;
             hipEvent_t* marks = nullptr;
             if (timeIt && begin == 0) {
@@ -942,7 +941,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                 ctx->evHasMarks[ctx->evUsed / 5] = 1;
             }
             HIP_TRY(ctx, launchWavefront(dof, collect, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
-                              wb, ctx->dCounters, dOut, ctx->minActive, ctx->minActiveShadow, marks, ctx->numCU));
+                              wb, ctx->dCounters, dOut, traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB),
+                              traceKnobs(ctx->minActiveShadow, ctx->parkAShadow, ctx->parkBShadow), marks, ctx->numCU));
         }
     }
     if (timeIt) {
@@ -956,6 +956,16 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
 {
     DevCounters c;
     HIP_TRY(ctx, hipMemcpy(&c, ctx->dCounters, sizeof c, hipMemcpyDeviceToHost));
+    if (getenv("RT_AMD_DEBUG_COUNTERS") && (c.loopIters[0][2] | c.loopIters[1][2])) {
+        // wave iterations of the traversal loop and the mean number of lanes that had work in them
+        const char* names[2] = { "path", "shadow" };
+        for (int k = 0; k < 2; k++) {
+            const double wi = c.loopIters[k][0] / 64.0, wl = c.loopIters[k][1] / 64.0, wr = c.loopIters[k][2] / 64.0;
+            const double li = k ? double(c.sInner) : double(c.inner - c.sInner), lt = k ? double(c.sTris) : double(c.tris - c.sTris);
+            fprintf(stderr, "[rt_amd] %s: inner wave-iters %.0f (%.1f lanes busy), leaf wave-iters %.0f (%.1f lanes testing), run() calls %.0f\n",
+                names[k], wi, wi > 0 ? li / wi : 0.0, wl, wl > 0 ? lt / wl : 0.0, wr);
+        }
+    }
     if (stats) {
         stats->rays = c.rays;
         stats->inner_nodes = c.inner;

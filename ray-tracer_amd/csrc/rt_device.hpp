@@ -167,7 +167,10 @@ struct DevCounters {
     unsigned long long rays, inner, tris;       // accumulated over the frame, all kernels
     unsigned long long sRays, sInner, sTris;    // the shadow kernel's share of them
     // work-queue heads and the node allocator; cleared before every batch
-    uint32_t next, nextShadow, nodes, shadowQueued;
+    uint32_t next, nextShadow, nodes, camQueued;
+    // counting launches only: iterations of the traversal loop summed over all 64 lanes of
+    // every wave (divide by 64 for wave iterations), [0] inner [1] leaf [2] calls of run()
+    unsigned long long loopIters[2][3]; // [0] path kernel, [1] shadow kernel
 };
 
 // ----------------------------------------------------------------------------

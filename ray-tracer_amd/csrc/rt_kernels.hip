@@ -401,7 +401,9 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
     L.phase = PH_NEWPIXEL;
     L.nrays = 0;
     L.r.nInner = L.r.nTris = 0;
+    L.r.itInner = L.r.itLeaf = L.r.itRuns = 0;
     L.r.cur = kRefNone;
+    L.r.pend = 0u;
     L.r.sp = 0;
     L.r.active = false;
     L.depth = 0;
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
                 break;
             continue;
         }
-        tracer.run(L.r, exhausted ? 0 : minActive);
+        tracer.run(L.r, exhausted ? (minActive & ~0xff) : minActive);
     }
 
     // ---- counters: one atomic per wave
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(256) void intersectKernel(const DevScene sc, const 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     RayState L;
     L.cur = kRefNone;
+    L.pend = 0u;
     L.sp = 0;
     L.active = false;
     L.nInner = L.nTris = 0;
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(256) void intersectKernel(const DevScene sc, const 
         const rt_ray r = rays[i];
         tracer.launch(L, ld3(r.origin), ld3(r.direction), r.t, K_RADIANCE);
     }
-    tracer.run(L, 0);
+    tracer.run(L, (16 << 8) | (32 << 16)); // every ray to completion, default switch points
     if (i >= n)
         return;
     tracer.spheres(L);

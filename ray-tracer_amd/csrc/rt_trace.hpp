@@ -28,11 +28,13 @@ struct RayState {
     float tmax, slen; // current closest t; the ray's original length (shadow rays)
     int hitPrim;      // primitive index, kHitNone, or -2 - sphere index
     int kind;
-    uint32_t cur;     // node reference being visited, kRefNone when finished
-    uint32_t li, le;  // inside a leaf: next primitive and end of the leaf
+    uint32_t cur;     // node reference to visit next, kRefNone when the stack has run dry
+    uint32_t pend;    // parked leaf reference whose primitives are still to be tested, 0 = none
+    uint32_t li, le;  // next primitive of the parked leaf and its end
     int sp;
     bool active;      // still inside the traversal loop
     uint32_t nInner, nTris;
+    uint32_t itInner, itLeaf, itRuns; // counting builds: loop iterations this lane sat through
 };
 
 __device__ __forceinline__ f3 rcp3(f3 d)
@@ -60,41 +62,57 @@ struct Tracer {
         r.sp++;
     }
 
-    // One BVHInterface::intersect call begins (src/bvh.cpp:337-358).  The root
-    // box test of src/bvh.cpp:253-259 happens here, so a ray that misses the
-    // whole scene never enters the traversal loop.
-    __device__ __forceinline__ void launch(RayState& r, f3 o, f3 d, float tmax, int kind) const
+    __device__ __forceinline__ void begin(RayState& r, f3 o, f3 d, float tmax, int kind) const
     {
         r.o = o;
         r.d = d;
-        const f3 inv = rcp3(d);
         r.tmax = tmax;
         r.slen = tmax;
         r.kind = kind;
         r.hitPrim = kHitNone;
         r.sp = 0;
         r.cur = kRefNone;
+        r.pend = 0u;
         r.active = false;
+    }
+
+    // The root box test of src/bvh.cpp:253-259: does the ray enter the scene's box at all?
+    __device__ __forceinline__ bool entersScene(f3 o, f3 inv) const
+    {
+        float e;
+        const f3 lo = { sc.rootLo[0], sc.rootLo[1], sc.rootLo[2] }, hi = { sc.rootHi[0], sc.rootHi[1], sc.rootHi[2] };
+        return sc.nPrims != 0 && boxTest(lo, hi, o, inv, kFltMax, e);
+    }
+
+    // Start the traversal at the root and set up the slab arithmetic of this ray.
+    __device__ __forceinline__ void enter(RayState& r, f3 inv) const
+    {
+        setCur(r, sc.rootRef);
+        // t(q) = ((gridMin + q*cell) - o) * inv = q*A + B.  Rounding bound of the
+        // fused form: (|q*A| + |B|) * 2^-22 for the inputs plus half an ulp of
+        // the result; (extent*|inv| + |B|) * 2^-20 covers it with room to spare.
+        const f3 gmin = { sc.gridMin[0], sc.gridMin[1], sc.gridMin[2] };
+        const f3 cell = { sc.gridCell[0], sc.gridCell[1], sc.gridCell[2] };
+        r.A = cell * inv;
+        const f3 B = (gmin - r.o) * inv;
+        const float k = 9.5367431640625e-7f; // 2^-20
+        const f3 err = { (65535.0f * fabsf(r.A.x) + fabsf(B.x)) * k, (65535.0f * fabsf(r.A.y) + fabsf(B.y)) * k,
+            (65535.0f * fabsf(r.A.z) + fabsf(B.z)) * k };
+        r.Bn = B - err;
+        r.Bf = B + err;
+        r.rot = (inv.x < 0.0f ? 16u : 0u) | (inv.y < 0.0f ? 16u << 5 : 0u) | (inv.z < 0.0f ? 16u << 10 : 0u);
+    }
+
+    // One BVHInterface::intersect call begins (src/bvh.cpp:337-358).  The root
+    // box test happens here, so a ray that misses the whole scene never enters
+    // the traversal loop.
+    __device__ __forceinline__ void launch(RayState& r, f3 o, f3 d, float tmax, int kind) const
+    {
+        begin(r, o, d, tmax, kind);
         if (accel) {
-            float e;
-            const f3 lo = { sc.rootLo[0], sc.rootLo[1], sc.rootLo[2] }, hi = { sc.rootHi[0], sc.rootHi[1], sc.rootHi[2] };
-            if (sc.nPrims != 0 && boxTest(lo, hi, o, inv, kFltMax, e)) {
-                r.active = true;
-                setCur(r, sc.rootRef);
-                // t(q) = ((gridMin + q*cell) - o) * inv = q*A + B.  Rounding bound of the
-                // fused form: (|q*A| + |B|) * 2^-22 for the inputs plus half an ulp of
-                // the result; (extent*|inv| + |B|) * 2^-20 covers it with room to spare.
-                const f3 gmin = { sc.gridMin[0], sc.gridMin[1], sc.gridMin[2] };
-                const f3 cell = { sc.gridCell[0], sc.gridCell[1], sc.gridCell[2] };
-                r.A = cell * inv;
-                const f3 B = (gmin - o) * inv;
-                const float k = 9.5367431640625e-7f; // 2^-20
-                const f3 err = { (65535.0f * fabsf(r.A.x) + fabsf(B.x)) * k, (65535.0f * fabsf(r.A.y) + fabsf(B.y)) * k,
-                    (65535.0f * fabsf(r.A.z) + fabsf(B.z)) * k };
-                r.Bn = B - err;
-                r.Bf = B + err;
-                r.rot = (inv.x < 0.0f ? 16u : 0u) | (inv.y < 0.0f ? 16u << 5 : 0u) | (inv.z < 0.0f ? 16u << 10 : 0u);
-            }
+            const f3 inv = rcp3(d);
+            if (entersScene(o, inv))
+                enter(r, inv);
         } else {
             // enableAccelStructure off: every primitive in order (src/bvh.cpp:344-351)
             for (uint32_t i = 0; i < sc.nPrims; i++) {
@@ -108,6 +126,13 @@ struct Tracer {
                 }
             }
         }
+    }
+
+    // The same for a ray already known to pass entersScene() (acceleration structure on).
+    __device__ __forceinline__ void launchInside(RayState& r, f3 o, f3 d, float tmax, int kind) const
+    {
+        begin(r, o, d, tmax, kind);
+        enter(r, rcp3(d));
     }
 
     // Conservative slab test against one quantised child box (three dwords, lo | hi << 16
@@ -128,44 +153,66 @@ struct Tracer {
         return tIn <= tOut && tIn <= r.tmax;
     }
 
-    // Make `ref` the node being visited; a leaf gets its primitive cursor.
+    // Make `ref` the node to visit next.
     __device__ __forceinline__ void setCur(RayState& r, uint32_t ref) const
     {
         r.cur = ref;
-        if (ref == kRefNone) {
-            r.active = false;
-        } else if (ref & kLeafFlag) {
-            r.li = ref & kLeafOffsetMask;
-            r.le = r.li + ((ref >> 27) & 15u);
-        }
+        r.active = true;
     }
 
-    // Shared traversal loop.  Every lane with a ray in flight is either at an
-    // inner node or inside a leaf; per iteration the wave runs ONE of the two
-    // code blocks, whichever more lanes are waiting for (ballot vote), so no
-    // lane ever idles behind a long run of the other kind and an iteration is
-    // never spent on a block that only a few lanes want.  An inner iteration
-    // visits one sibling pair, a leaf iteration tests one primitive; the order
-    // of the tests along one ray is unchanged (near child first, the
-    // primitives of a leaf in order), only the interleaving between lanes is.
-    // `minActive`: leave as soon as fewer lanes than this still have a ray in
-    // flight (0 = run every ray to completion).
-    __device__ __forceinline__ void run(RayState& r, int minActive) const
+    // Shared traversal loop.  A lane that reaches a leaf does not test it on the
+    // spot: it parks the leaf in `pend` and goes on down the tree (pops the next
+    // node), so that most lanes can still take inner steps while they already
+    // hold triangle work; only with a second leaf in hand does a lane have to
+    // wait.  Per iteration the wave runs ONE of the two code blocks -- an inner
+    // step (one sibling pair) for every lane that has a node, or one triangle
+    // test for every lane that has a parked leaf -- whichever more lanes are
+    // ready for (ballot vote).  Along one ray the near child still goes first
+    // and the primitives of a leaf are tested in order; a parked leaf only sees
+    // its ray's t a few steps later than it would have, which changes how many
+    // boxes are culled but not which hit is the closest.
+    // `knobs`: bits 0-7 minActive -- leave as soon as fewer lanes than this still have a
+    // ray in flight (0 = run every ray to completion); bits 8-15 and 16-23 the two
+    // switch points between inner steps and triangle tests described in the loop.
+    __device__ __forceinline__ void run(RayState& r, int knobs) const
     {
+        const int minActive = knobs & 0xff, voteScale = (knobs >> 8) & 0xff, voteBias = (knobs >> 16) & 0xff;
         const uint32_t rx = r.rot & 31u, ry = (r.rot >> 5) & 31u, rz = (r.rot >> 10) & 31u;
+        if (STATS)
+            r.itRuns++;
         for (;;) {
-            const bool atLeaf = r.active && (r.cur & kLeafFlag);
-            const bool atInner = r.active && !(r.cur & kLeafFlag);
-            const int nLeaf = __popcll(__ballot(atLeaf)), nInner = __popcll(__ballot(atInner));
-            if (nLeaf + nInner == 0 || nLeaf + nInner < minActive)
+            if ((int32_t)r.cur < 0 && r.pend == 0u) { // a leaf and a free slot: park it, take the next node
+                const uint32_t count = (r.cur >> 27) & 15u;
+                r.pend = count ? r.cur : 0u; // an empty leaf is dropped here
+                r.li = r.cur & kLeafOffsetMask;
+                r.le = r.li + count;
+                r.cur = pop(r);
+            }
+            const bool canInner = r.cur < kRefNone; // leaf refs have the top bit set, kRefNone is the largest inner value
+            const bool canLeaf = r.pend != 0u;
+            const int nInner = __popcll(__ballot(canInner)), nLeaf = __popcll(__ballot(canLeaf));
+            const int alive = __popcll(__ballot(canLeaf || r.cur != kRefNone));
+            if (alive == 0 || alive < minActive)
                 break;
-            if (nInner >= nLeaf) {
-                if (atInner)
+            // vote: triangles when the lanes holding a leaf outnumber (scaled, biased) those with a node
+            bool leafMode = 16 * nLeaf > voteScale * nInner + 16 * (voteBias - 32);
+            if (nInner == 0)
+                leafMode = true;
+            if (nLeaf == 0)
+                leafMode = false;
+            if (!leafMode) {
+                if (STATS)
+                    r.itInner++;
+                if (canInner)
                     innerStep(r, rx, ry, rz);
-            } else if (atLeaf) {
-                leafStep(r);
+            } else {
+                if (STATS)
+                    r.itLeaf++;
+                if (canLeaf)
+                    leafStep(r);
             }
         }
+        r.active = r.pend != 0u || r.cur != kRefNone;
     }
 
     // One sibling-pair record (32 B): test both children, descend into the nearer.
@@ -178,45 +225,35 @@ struct Tracer {
         float eL, eR;
         const bool hL = qboxTest(w0.x, w0.y, w0.z, rx, ry, rz, r, eL);
         const bool hR = qboxTest(w0.w, w1.x, w1.y, rx, ry, rz, r, eR);
-        uint32_t next;
-        if (hL && hR) {
-            // nearer child first; on a tie the right child, as in src/bvh.cpp:301-307
-            const bool leftFirst = eL < eR;
-            push(r, leftFirst ? w1.w : w1.z);
-            next = leftFirst ? w1.z : w1.w;
-        } else if (hL) {
-            next = w1.z;
-        } else if (hR) {
-            next = w1.w;
-        } else {
-            next = pop(r);
-        }
-        setCur(r, next);
+        // nearer child first; on a tie the right child, as in src/bvh.cpp:301-307
+        const bool takeLeft = hL && (!hR || eL < eR);
+        const uint32_t nearRef = takeLeft ? w1.z : w1.w, farRef = takeLeft ? w1.w : w1.z;
+        if (hL && hR)
+            push(r, farRef);
+        r.cur = (hL || hR) ? nearRef : pop(r);
     }
 
-    // One primitive of the current leaf, in order (src/bvh.cpp:272-279).
+    // One primitive of the parked leaf, in order (src/bvh.cpp:272-279).
     __device__ __forceinline__ void leafStep(RayState& r) const
     {
-        if (r.li < r.le) {
-            float t;
-            if (STATS)
-                r.nTris++;
-            if (triangleTestLazy(sc.tris, r.li, r.o, r.d, r.tmax, t)) {
-                r.tmax = t;
-                r.hitPrim = (int)r.li;
-                // Binary visibility only asks whether the closest hit lies more
-                // than 1e-4 before the target (src/light.cpp:101-104); any hit
-                // that does settles it, the closest one is at least as near.
-                if (r.kind == K_SHADOW_ANY && fabsf(t - r.slen) > 0.0001f) {
-                    r.cur = kRefNone;
-                    r.active = false;
-                    return;
-                }
+        float t;
+        if (STATS)
+            r.nTris++;
+        if (triangleTestLazy(sc.tris, r.li, r.o, r.d, r.tmax, t)) {
+            r.tmax = t;
+            r.hitPrim = (int)r.li;
+            // Binary visibility only asks whether the closest hit lies more
+            // than 1e-4 before the target (src/light.cpp:101-104); any hit
+            // that does settles it, the closest one is at least as near.
+            if (r.kind == K_SHADOW_ANY && fabsf(t - r.slen) > 0.0001f) {
+                r.cur = kRefNone;
+                r.pend = 0u;
+                return;
             }
-            r.li++;
         }
+        r.li++;
         if (r.li >= r.le)
-            setCur(r, pop(r));
+            r.pend = 0u;
     }
 
     // Spheres are tested after the BVH, in order, against the current ray.t

@@ -27,43 +27,9 @@
 // both produce the same bits.
 
 #include "rt_trace.hpp"
+#include "rt_wavefront.hpp"
 
 namespace rt {
-
-// One shaded hit.  A: what shading needs.  B: links and bookkeeping.
-struct NodeB {
-    uint32_t path; // path index inside the batch
-    int32_t depth;
-    int32_t child; // kChildNone, kChildMiss (value in cv), or node index
-    float cv[3];
-    uint32_t pad[2];
-};
-constexpr int32_t kChildNone = -1, kChildMiss = -2;
-constexpr int32_t kPathMiss = -1;
-
-struct WfBuffers {
-    int32_t* pathHead;   // [paths]  first node or kPathMiss
-    uint8_t* pathCount;  // [paths]  nodes of the path
-    uint32_t* pathBase;  // [paths]  nodes of earlier paths of the same pixel
-    float* pathEnv;      // [paths*3] environment colour of a camera ray that missed (env map on)
-    float4* nodeA;       // [nodes*4] P.xyz N.x | N.yz rd.xy | rd.z kd.xyz | ks.xyz shininess
-    NodeB* nodeB;        // [nodes]
-    float* contrib;      // [nodes * slots * 3]
-    float4* srays;       // [nodes * slots * 3] shadow ray: origin.xyz length | direction.xyz 0 | light colour.xyz 0
-    uint8_t* svis;       // [nodes * slots]     1 = light sample visible
-    uint32_t maxNodes;
-};
-
-struct WfParams {
-    uint32_t slotBegin;  // first local pixel slot of this batch
-    uint32_t nSlots;     // pixel slots in this batch (multiple of 64)
-    uint32_t R;          // camera rays per pixel
-    uint32_t slots;      // light-sample slots per hit: sum over lights of (point ? 1 : shadowSamples)
-    uint32_t drawsPerHit;
-    uint32_t pixDraws;   // draws of the pixel-sample stretch
-    uint32_t mainStart;  // position of the first light-sample draw
-    uint32_t chunk;      // work items per queue fetch
-};
 
 // state after k draws from `state` (src/sampler.h:18), O(log k)
 __device__ __forceinline__ uint32_t lcgSkip(uint32_t state, uint32_t k)
@@ -132,50 +98,108 @@ __device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
 }
 
 // ---------------------------------------------------------------------------
-// 1. camera rays and their mirror chains
+// 1a. camera rays, one lane per ray: generatePixelRays* and the root box test of
+//     BVHInterface::intersect.  With the default camera most rays never enter
+//     the scene's box; those are finished here (a miss, src/recursive.cpp:29-32)
+//     and only the others are queued for the traversal kernel, so its
+//     wavefronts spend their time on rays that have something to traverse.
 // ---------------------------------------------------------------------------
-template <bool DOF, bool STATS>
-__global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevCamera cam, const DevFeat ft, const DevFrame fr,
-    const WfParams wp, const WfBuffers wb, DevCounters* __restrict__ ctr, int minActive)
+template <bool DOF>
+__global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const DevCamera cam, const DevFeat ft, const DevFrame fr,
+    const WfParams wp, const WfBuffers wb, DevCounters* __restrict__ ctr)
+{
+    __shared__ uint32_t waveCount[4];
+    __shared__ uint32_t blockBase;
+    const Tracer<false> tracer { sc, ft.accel, nullptr };
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t total = wp.nSlots * wp.R;
+    const uint32_t path = blockIdx.x * blockDim.x + threadIdx.x;
+    bool queue = false, enters = false;
+    f3 o = { 0.0f, 0.0f, 0.0f }, d = { 0.0f, 0.0f, 0.0f };
+    if (path < total) {
+        const uint32_t slot = wp.slotBegin + path / wp.R, i = path % wp.R;
+        int px, py;
+        if (slotToPixel(fr, slot, px, py)) { // padding pixels of partial edge tiles have no rays
+            const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
+            const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
+            uint32_t sPix = (ft.spp > 1) ? lcgSkip(seed, 2u * (i / dofN)) : seed;
+            uint32_t sLens = (DOF && ft.dof) ? lcgSkip(seed, wp.pixDraws + 2u * i) : seed;
+            f3 pof = { 0.0f, 0.0f, 0.0f };
+            cameraRay<DOF>(cam, ft, fr, px, py, i - (i % dofN), sPix, sLens, pof, o, d);
+            enters = ft.accel && tracer.entersScene(o, rcp3(d));
+            // without the acceleration structure, or with spheres in the scene, every ray has work left
+            queue = enters || !ft.accel || sc.nSpheres != 0;
+            if (!queue) {
+                wb.pathHead[path] = kPathMiss;
+                wb.pathCount[path] = 0;
+                if (ft.envMap) {
+                    const f3 env = sampleEnvironmentMap(sc, ft, d);
+                    wb.pathEnv[3u * path + 0] = env.x;
+                    wb.pathEnv[3u * path + 1] = env.y;
+                    wb.pathEnv[3u * path + 2] = env.z;
+                }
+            }
+        }
+    }
+    // one queue reservation per block
+    const unsigned long long qm = __ballot(queue);
+    if (lane == 0)
+        waveCount[wave] = (uint32_t)__popcll(qm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
+        blockBase = n ? atomicAdd(&ctr->camQueued, n) : 0u;
+    }
+    __syncthreads();
+    if (queue) {
+        uint32_t idx = blockBase + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; w++)
+            idx += waveCount[w];
+        wb.camRays[2u * (size_t)idx + 0] = make_float4(o.x, o.y, o.z, __uint_as_float(path));
+        wb.camRays[2u * (size_t)idx + 1] = make_float4(d.x, d.y, d.z, enters ? 1.0f : 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 1b. the queued camera rays and their mirror chains
+// ---------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+    DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
     const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x };
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = wp.nSlots * wp.R;
+    const uint32_t total = ctr->camQueued;
 
     RayState r;
     r.active = false;
     r.cur = kRefNone;
+    r.pend = 0u;
     r.sp = 0;
     r.nInner = r.nTris = 0;
-    uint32_t path = 0, nrays = 0;
+    r.itInner = r.itLeaf = r.itRuns = 0;
+    uint32_t path = 0, item = 0, nrays = 0;
     int depth = 0, prev = -1, count = 0;
     bool have = false, dead = false;
     WaveQueue q;
 
     for (;;) {
-        // ---- lanes without a path take the next one and shoot its camera ray
+        // ---- lanes without a path take the next queued camera ray
         for (int round = 0; round < 2; round++) {
             bool want = !have && !dead;
-            q.fetch(want, path, dead, &ctr->next, total, wp.chunk, lane);
+            q.fetch(want, item, dead, &ctr->next, total, wp.chunk, lane);
             if (!have && !dead && !want) {
-                const uint32_t slot = wp.slotBegin + path / wp.R, i = path % wp.R;
-                int px, py;
-                if (slotToPixel(fr, slot, px, py)) {
-                    const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
-                    const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
-                    uint32_t sPix = (ft.spp > 1) ? lcgSkip(seed, 2u * (i / dofN)) : seed;
-                    uint32_t sLens = (DOF && ft.dof) ? lcgSkip(seed, wp.pixDraws + 2u * i) : seed;
-                    f3 pof = { 0.0f, 0.0f, 0.0f }, o, d;
-                    cameraRay<DOF>(cam, ft, fr, px, py, i - (i % dofN), sPix, sLens, pof, o, d);
-                    tracer.launch(r, o, d, kFltMax, K_RADIANCE);
-                    nrays++;
-                    have = true;
-                    depth = 0;
-                    prev = -1;
-                    count = 0;
-                }
-                // padding pixel of a partial edge tile: nothing to do, take another path
+                const float4 c0 = wb.camRays[2u * (size_t)item + 0], c1 = wb.camRays[2u * (size_t)item + 1];
+                path = __float_as_uint(c0.w);
+                if (c1.w != 0.0f)
+                    tracer.launchInside(r, { c0.x, c0.y, c0.z }, { c1.x, c1.y, c1.z }, kFltMax, K_RADIANCE);
+                else
+                    tracer.launch(r, { c0.x, c0.y, c0.z }, { c1.x, c1.y, c1.z }, kFltMax, K_RADIANCE);
+                have = true;
+                depth = 0;
+                prev = -1;
+                count = 0;
             }
             // ---- paths whose ray has finished: record the hit, continue the chain or retire
             while (have && !r.active) {
@@ -203,10 +227,15 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevCa
                 // one node per shaded hit; slots are handed out per wave
                 const unsigned long long am = __ballot(true);
                 const int leader = __builtin_ctzll(am);
+#ifdef RT_EXP_NOATOMIC
+                const uint32_t idx = path * (uint32_t)(ft.maxDepth + 1) + (uint32_t)depth;
+                (void)leader;
+#else
                 uint32_t base = 0;
                 if (lane == (uint32_t)leader)
                     base = atomicAdd(&ctr->nodes, (uint32_t)__popcll(am));
                 const uint32_t idx = __shfl(base, leader) + __popcll(am & ((1ull << lane) - 1ull));
+#endif
                 if (idx >= wb.maxNodes) { // cannot happen: the pool holds the worst case of the batch
                     wb.pathCount[path] = (uint8_t)count;
                     have = false;
@@ -251,15 +280,20 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevCa
                 break;
             continue;
         }
-        tracer.run(r, q.exhausted ? 0 : minActive);
+        tracer.run(r, q.exhausted ? (minActive & ~0xff) : minActive);
     }
 
     const unsigned long long rs = waveSum(nrays), ni = waveSum(r.nInner), nt = waveSum(r.nTris);
+    const unsigned long long ii = waveSum(r.itInner), il = waveSum(r.itLeaf), ir = waveSum(r.itRuns);
     if (lane == 0) {
-        atomicAdd(&ctr->rays, rs);
+        // reflection rays counted here; every camera ray of a real pixel is one intersect call, traced or not
+        atomicAdd(&ctr->rays, rs + ((blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)wp.validPaths : 0ull));
         if (STATS) {
             atomicAdd(&ctr->inner, ni);
             atomicAdd(&ctr->tris, nt);
+            atomicAdd(&ctr->loopIters[0][0], ii);
+            atomicAdd(&ctr->loopIters[0][1], il);
+            atomicAdd(&ctr->loopIters[0][2], ir);
         }
     }
 }
@@ -365,8 +399,10 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     RayState r;
     r.active = false;
     r.cur = kRefNone;
+    r.pend = 0u;
     r.sp = 0;
     r.nInner = r.nTris = 0;
+    r.itInner = r.itLeaf = r.itRuns = 0;
     uint32_t item = 0;
     bool have = false, dead = false;
     WaveQueue q;
@@ -394,16 +430,20 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
                 break;
             continue;
         }
-        tracer.run(r, q.exhausted ? 0 : minActive);
+        tracer.run(r, q.exhausted ? (minActive & ~0xff) : minActive);
     }
 
     const unsigned long long ni = waveSum(r.nInner), nt = waveSum(r.nTris);
+    const unsigned long long ii = waveSum(r.itInner), il = waveSum(r.itLeaf), ir = waveSum(r.itRuns);
     if (lane == 0) {
         if (STATS) {
             atomicAdd(&ctr->inner, ni);
             atomicAdd(&ctr->tris, nt);
             atomicAdd(&ctr->sInner, ni);
             atomicAdd(&ctr->sTris, nt);
+            atomicAdd(&ctr->loopIters[1][0], ii);
+            atomicAdd(&ctr->loopIters[1][1], il);
+            atomicAdd(&ctr->loopIters[1][2], ir);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0 && ft.shadows) { // every (hit, sample) is one intersect call
             const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
@@ -515,21 +555,14 @@ __global__ void combineKernel(const DevScene sc, const DevFeat ft, const DevFram
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-typedef void (*PathFn)(const DevScene, const DevCamera, const DevFeat, const DevFrame, const WfParams, const WfBuffers,
-    DevCounters*, int);
 typedef void (*ShadowFn)(const DevScene, const DevFeat, const WfParams, const WfBuffers, DevCounters*, int);
 
-static PathFn pathVariant(bool dof, bool stats)
-{
-    if (dof)
-        return stats ? pathKernel<true, true> : pathKernel<true, false>;
-    return stats ? pathKernel<false, true> : pathKernel<false, false>;
-}
+static ShadowFn pathVariant(bool stats) { return stats ? pathKernel<true> : pathKernel<false>; }
 static ShadowFn shadowVariant(bool stats) { return stats ? shadowTraceKernel<true> : shadowTraceKernel<false>; }
 
-hipError_t wavefrontOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks)
+hipError_t wavefrontOccupancy(bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks)
 {
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(pathBlocks, pathVariant(dof, stats), blockThreads, ldsBytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(pathBlocks, pathVariant(stats), blockThreads, ldsBytes);
     if (e != hipSuccess)
         return e;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(shadowBlocks, shadowVariant(stats), blockThreads, ldsBytes);
@@ -540,8 +573,12 @@ hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlock
     const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU)
 {
     // marks (optional, 3 events): after the path kernel, before and after the shadow-ray traversal
-    hipLaunchKernelGGL(pathVariant(dof, stats), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, cam, ft, fr, wp, wb,
-        ctr, minActive);
+    const int cb = (int)(((size_t)wp.nSlots * wp.R + 255) / 256);
+    if (dof)
+        hipLaunchKernelGGL(cameraKernel<true>, dim3(cb), dim3(256), 0, stream, sc, cam, ft, fr, wp, wb, ctr);
+    else
+        hipLaunchKernelGGL(cameraKernel<false>, dim3(cb), dim3(256), 0, stream, sc, cam, ft, fr, wp, wb, ctr);
+    hipLaunchKernelGGL(pathVariant(stats), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActive);
     if (marks)
         (void)hipEventRecord(marks[0], stream);
     const int pb = (int)((wp.nSlots + 255) / 256);

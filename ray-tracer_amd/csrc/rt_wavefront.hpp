@@ -1,0 +1,51 @@
+// rt_wavefront.hpp -- buffers and launch interface of the queue-based renderer
+// (rt_wavefront.hip), shared with the host side (rt_capi.cpp).
+#pragma once
+
+#include "rt_device.hpp"
+
+namespace rt {
+
+// One shaded hit.  A: what shading needs.  B: links and bookkeeping.
+struct NodeB {
+    uint32_t path; // path index inside the batch
+    int32_t depth;
+    int32_t child; // kChildNone, kChildMiss (value in cv), or node index
+    float cv[3];
+    uint32_t pad[2];
+};
+constexpr int32_t kChildNone = -1, kChildMiss = -2;
+constexpr int32_t kPathMiss = -1;
+
+struct WfBuffers {
+    int32_t* pathHead;   // [paths]  first node or kPathMiss
+    uint8_t* pathCount;  // [paths]  nodes of the path
+    uint32_t* pathBase;  // [paths]  nodes of earlier paths of the same pixel
+    float* pathEnv;      // [paths*3] environment colour of a camera ray that missed (env map on)
+    float4* nodeA;       // [nodes*4] P.xyz N.x | N.yz rd.xy | rd.z kd.xyz | ks.xyz shininess
+    NodeB* nodeB;        // [nodes]
+    float* contrib;      // [nodes * slots * 3]
+    float4* srays;       // [nodes * slots * 3] shadow ray: origin.xyz length | direction.xyz 0 | light colour.xyz 0
+    uint8_t* svis;       // [nodes * slots]     1 = light sample visible
+    float4* camRays;     // [paths*2] camera rays that need tracing: origin.xyz path(bits) | direction.xyz enters-the-scene-box flag
+    uint32_t maxNodes;
+};
+
+struct WfParams {
+    uint32_t slotBegin;  // first local pixel slot of this batch
+    uint32_t nSlots;     // pixel slots in this batch (multiple of 64)
+    uint32_t R;          // camera rays per pixel
+    uint32_t slots;      // light-sample slots per hit: sum over lights of (point ? 1 : shadowSamples)
+    uint32_t drawsPerHit;
+    uint32_t pixDraws;   // draws of the pixel-sample stretch
+    uint32_t mainStart;  // position of the first light-sample draw
+    uint32_t chunk;      // work items per queue fetch
+    uint32_t validPaths; // camera rays of the batch's real (non-padding) pixels
+};
+
+hipError_t wavefrontOccupancy(bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
+hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
+    hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
+    const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
+
+} // namespace rt
