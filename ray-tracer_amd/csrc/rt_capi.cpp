@@ -73,6 +73,7 @@ struct rt_ctx {
     // switch points of the traversal loop between inner steps and triangle tests (rt_trace.hpp):
     // lanes blocked before triangles are tested; lanes still holding a leaf when inner steps resume
     int parkA = 16, parkB = 32, parkAShadow = 16, parkBShadow = 32;
+    int chunkPath = 128, chunkShadow = 512; // rays a wavefront takes from the queue at a time
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
     int forcePerPixel = 0; // 1 = always use the per-pixel kernel
@@ -154,6 +155,10 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->parkAShadow = atoi(s);
     if (const char* s = getenv("RT_AMD_PARK_B_SHADOW"))
         ctx->parkBShadow = atoi(s);
+    if (const char* s = getenv("RT_AMD_CHUNK_PATH"))
+        ctx->chunkPath = std::max(64, atoi(s));
+    if (const char* s = getenv("RT_AMD_CHUNK_SHADOW"))
+        ctx->chunkShadow = std::max(64, atoi(s));
     if (const char* s = getenv("RT_AMD_LOGIC_ROUNDS"))
         ctx->logicRounds = std::max(1, atoi(s));
     if (const char* s = getenv("RT_AMD_BLOCKS_PER_CU"))
@@ -872,19 +877,32 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         wp.drawsPerHit = drawsPerHit;
         wp.pixDraws = (F.numPixelSamples > 1 ? 2u : 0u) * ft.camRays;
         wp.mainStart = wp.pixDraws + (F.enableDepthOfField ? 2u * ft.camRays * F.numDepthOfFieldSamples : 0u);
-        wp.chunk = 512;
+        wp.chunk = ctx->chunkShadow;
+        wp.chunkPath = ctx->chunkPath;
         if (wp.R == 0 || wp.R > 65535u)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
+        const bool dof = F.enableDepthOfField != 0;
+        int pathPerCU = ctx->blocksPerCU, shadowPerCU = ctx->blocksPerCU;
+        if (pathPerCU <= 0) {
+            HIP_TRY(ctx, wavefrontOccupancy(collect, blockThreads, lds, &pathPerCU, &shadowPerCU));
+            pathPerCU = std::max(1, std::min(pathPerCU, 8));
+            shadowPerCU = std::max(1, std::min(shadowPerCU, 8));
+        }
+        // every wavefront of the path kernel may leave part of its last block of node slots unused
+        const uint64_t nodeSlack = static_cast<uint64_t>(ctx->numCU) * pathPerCU * (blockThreads / 64) * kNodeBlock;
         const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * (F.enableReflections ? F.maxRayDepth + 1 : 1);
         const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + 32 + (F.enableEnvironmentMap ? 12 : 0))
             + nodesPerPixel * (64 + sizeof(NodeB) + (12ull + 48 + 1) * std::max(1u, slots));
         uint64_t batchSlots = ctx->workspaceCap / std::max<uint64_t>(1, bytesPerPixel);
         batchSlots = std::min<uint64_t>(batchSlots, 0x7fffffffull / wp.R);                                       // path index in 31 bits
-        batchSlots = std::min<uint64_t>(batchSlots, 0xffffffffull / (nodesPerPixel * std::max(1u, slots)));      // item index in 32 bits
+        const uint64_t nodeCap = 0xffffffffull / std::max(1u, slots); // item index (node * slots + slot) in 32 bits
+        if (nodeCap <= nodeSlack)
+            return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u light samples per hit exceed the supported count", slots);
+        batchSlots = std::min<uint64_t>(batchSlots, (nodeCap - nodeSlack) / nodesPerPixel);
         batchSlots = std::min<uint64_t>(batchSlots, fr.nWork) & ~63ull;
         if (batchSlots == 0)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: one tile of this frame needs more than the %zu-byte workspace", ctx->workspaceCap);
-        const uint64_t paths = batchSlots * wp.R, maxNodes = batchSlots * nodesPerPixel;
+        const uint64_t paths = batchSlots * wp.R, maxNodes = batchSlots * nodesPerPixel + nodeSlack;
         const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, slots);
         const size_t want[10] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
             F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
@@ -913,13 +931,6 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         wb.camRays = static_cast<float4*>(ctx->wsPtr[9]);
         wb.maxNodes = static_cast<uint32_t>(maxNodes);
 
-        const bool dof = F.enableDepthOfField != 0;
-        int pathPerCU = ctx->blocksPerCU, shadowPerCU = ctx->blocksPerCU;
-        if (pathPerCU <= 0) {
-            HIP_TRY(ctx, wavefrontOccupancy(collect, blockThreads, lds, &pathPerCU, &shadowPerCU));
-            pathPerCU = std::max(1, std::min(pathPerCU, 8));
-            shadowPerCU = std::max(1, std::min(shadowPerCU, 8));
-        }
         for (uint64_t begin = 0; begin < fr.nWork; begin += batchSlots) {
             wp.slotBegin = static_cast<uint32_t>(begin);
             wp.nSlots = static_cast<uint32_t>(std::min<uint64_t>(batchSlots, fr.nWork - begin));

@@ -179,7 +179,11 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFe
     r.sp = 0;
     r.nInner = r.nTris = 0;
     r.itInner = r.itLeaf = r.itRuns = 0;
-    uint32_t path = 0, item = 0, nrays = 0;
+    uint32_t path = 0, item = 0, nrays = 0, made = 0;
+    __shared__ uint32_t nodeBlkAll[4][2]; // per wave: next free slot and end of its block of node slots
+    volatile uint32_t* nodeBlk = nodeBlkAll[threadIdx.x >> 6];
+    if (lane == 0)
+        nodeBlk[0] = nodeBlk[1] = 0u;
     int depth = 0, prev = -1, count = 0;
     bool have = false, dead = false;
     WaveQueue q;
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFe
         // ---- lanes without a path take the next queued camera ray
         for (int round = 0; round < 2; round++) {
             bool want = !have && !dead;
-            q.fetch(want, item, dead, &ctr->next, total, wp.chunk, lane);
+            q.fetch(want, item, dead, &ctr->next, total, wp.chunkPath, lane);
             if (!have && !dead && !want) {
                 const float4 c0 = wb.camRays[2u * (size_t)item + 0], c1 = wb.camRays[2u * (size_t)item + 1];
                 path = __float_as_uint(c0.w);
@@ -224,18 +228,28 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFe
                     break;
                 }
                 const HitCtx h = shadeHit(sc, ft, r);
-                // one node per shaded hit; slots are handed out per wave
+                // One node per shaded hit.  Every wave owns a block of kNodeBlock consecutive slots of
+                // the pool and hands them out itself; only a new block costs an atomic (one address
+                // takes well under a hundred of them per microsecond, far fewer than there are hits).
                 const unsigned long long am = __ballot(true);
-                const int leader = __builtin_ctzll(am);
-#ifdef RT_EXP_NOATOMIC
-                const uint32_t idx = path * (uint32_t)(ft.maxDepth + 1) + (uint32_t)depth;
-                (void)leader;
-#else
-                uint32_t base = 0;
-                if (lane == (uint32_t)leader)
-                    base = atomicAdd(&ctr->nodes, (uint32_t)__popcll(am));
-                const uint32_t idx = __shfl(base, leader) + __popcll(am & ((1ull << lane) - 1ull));
-#endif
+                const uint32_t n = (uint32_t)__popcll(am), rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+                // (kept in LDS: only some lanes are here, all of the wave must see the update)
+                const uint32_t nodeCur = nodeBlk[0], nodeEnd = nodeBlk[1];
+                const uint32_t rem = nodeEnd - nodeCur;
+                uint32_t fresh = 0;
+                if (n > rem) {
+                    const int leader = __builtin_ctzll(am);
+                    if (lane == (uint32_t)leader)
+                        fresh = atomicAdd(&ctr->nodes, kNodeBlock);
+                    fresh = __shfl(fresh, leader);
+                }
+                const uint32_t idx = rank < rem ? nodeCur + rank : fresh + (rank - rem);
+                if (rank == 0) {
+                    nodeBlk[0] = n > rem ? fresh + (n - rem) : nodeCur + n;
+                    if (n > rem)
+                        nodeBlk[1] = fresh + kNodeBlock;
+                }
+                made++;
                 if (idx >= wb.maxNodes) { // cannot happen: the pool holds the worst case of the batch
                     wb.pathCount[path] = (uint8_t)count;
                     have = false;
@@ -283,11 +297,19 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFe
         tracer.run(r, q.exhausted ? (minActive & ~0xff) : minActive);
     }
 
+    // the unused tail of the wave's last block: slots that hold no hit
+    for (uint32_t i = nodeBlk[0] + lane, e = nodeBlk[1]; i < e && i < wb.maxNodes; i += 64u)
+        wb.nodeB[i].path = kDeadNode;
+
+    // every (hit, light sample) will be one intersect call of the shadow stage
+    const unsigned long long srays = ft.shadows ? waveSum(made) * wp.slots : 0ull;
     const unsigned long long rs = waveSum(nrays), ni = waveSum(r.nInner), nt = waveSum(r.nTris);
     const unsigned long long ii = waveSum(r.itInner), il = waveSum(r.itLeaf), ir = waveSum(r.itRuns);
     if (lane == 0) {
         // reflection rays counted here; every camera ray of a real pixel is one intersect call, traced or not
-        atomicAdd(&ctr->rays, rs + ((blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)wp.validPaths : 0ull));
+        atomicAdd(&ctr->rays, rs + srays + ((blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)wp.validPaths : 0ull));
+        if (srays)
+            atomicAdd(&ctr->sRays, srays);
         if (STATS) {
             atomicAdd(&ctr->inner, ni);
             atomicAdd(&ctr->tris, nt);
@@ -349,6 +371,13 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
                 drawPrefix += n * perSample;
             }
             const NodeB nb = wb.nodeB[node];
+            float4* sr = wb.srays + 3u * (size_t)item;
+            if (nb.path == kDeadNode) { // a slot no hit was written to: no ray, no light
+                sr[0] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+                sr[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                wb.svis[item] = 0;
+                continue;
+            }
             const float4 a0 = wb.nodeA[4u * (size_t)node];
             const f3 P = { a0.x, a0.y, a0.z };
             int px, py;
@@ -377,7 +406,6 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
             } else { // src/light.cpp:270-272: no ray; keep minus the direction to the light
                 d = -normalize(pos - P);
             }
-            float4* sr = wb.srays + 3u * (size_t)item;
             sr[0] = make_float4(pos.x, pos.y, pos.z, len);
             sr[1] = make_float4(d.x, d.y, d.z, 0.0f);
             sr[2] = make_float4(col.x, col.y, col.z, 0.0f);
@@ -413,8 +441,10 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
         if (!have && !dead && !want) {
             const float4* sr = wb.srays + 3u * (size_t)item;
             const float4 a = sr[0], b = sr[1];
-            tracer.launch(r, { a.x, a.y, a.z }, { b.x, b.y, b.z }, a.w, K_SHADOW_ANY);
-            have = true;
+            if (a.w >= 0.0f) { // a negative length marks the slot of a node that holds no hit
+                tracer.launch(r, { a.x, a.y, a.z }, { b.x, b.y, b.z }, a.w, K_SHADOW_ANY);
+                have = true;
+            }
         }
         if (have && !r.active) {
             if (sc.nSpheres)
@@ -444,12 +474,6 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
             atomicAdd(&ctr->loopIters[1][0], ii);
             atomicAdd(&ctr->loopIters[1][1], il);
             atomicAdd(&ctr->loopIters[1][2], ir);
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0 && ft.shadows) { // every (hit, sample) is one intersect call
-            const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
-            const unsigned long long n = (unsigned long long)nNodes * wp.slots;
-            atomicAdd(&ctr->rays, n);
-            atomicAdd(&ctr->sRays, n);
         }
     }
 }

@@ -16,6 +16,8 @@ struct NodeB {
 };
 constexpr int32_t kChildNone = -1, kChildMiss = -2;
 constexpr int32_t kPathMiss = -1;
+constexpr uint32_t kDeadNode = 0xffffffffu; // NodeB::path of a pool slot no hit was written to
+constexpr uint32_t kNodeBlock = 256;         // node slots a wavefront reserves at a time (>= 64)
 
 struct WfBuffers {
     int32_t* pathHead;   // [paths]  first node or kPathMiss
@@ -39,7 +41,8 @@ struct WfParams {
     uint32_t drawsPerHit;
     uint32_t pixDraws;   // draws of the pixel-sample stretch
     uint32_t mainStart;  // position of the first light-sample draw
-    uint32_t chunk;      // work items per queue fetch
+    uint32_t chunk;      // shadow rays per queue fetch
+    uint32_t chunkPath;  // camera rays per queue fetch
     uint32_t validPaths; // camera rays of the batch's real (non-padding) pixels
 };
 
