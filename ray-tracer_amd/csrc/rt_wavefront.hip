@@ -525,55 +525,76 @@ __device__ __forceinline__ f3 nodeLo(const DevScene& sc, const DevFeat& ft, cons
     return clamp01(Lo);
 }
 
-__global__ void combineKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp, const WfBuffers wb,
-    float* __restrict__ out)
+// The value renderRay returns for one camera ray: its chain of hits folded from the deepest one up.
+__device__ __forceinline__ f3 pathValue(const DevScene& sc, const DevFeat& ft, const WfParams& wp, const WfBuffers& wb, uint32_t path)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= wp.nSlots)
-        return;
-    int px, py;
-    if (!slotToPixel(fr, wp.slotBegin + s, px, py))
-        return;
-    f3 L = mk3(0.0f);
-    for (uint32_t i = 0; i < wp.R; i++) {
-        const uint32_t path = s * wp.R + i;
-        const int32_t head = wb.pathHead[path];
-        f3 v;
-        if (head == kPathMiss) {
-            v = ft.envMap ? ld3(wb.pathEnv + 3u * path) : mk3(0.0f);
-        } else {
-            int32_t chain[kMaxDepth + 1];
-            int n = 0;
-            int32_t cur = head, link = kChildNone;
-            f3 cv = mk3(0.0f);
-            while (n <= kMaxDepth) {
-                chain[n++] = cur;
-                const NodeB nb = wb.nodeB[cur];
-                link = nb.child;
-                cv = ld3(nb.cv);
-                if (link < 0)
-                    break;
-                cur = link;
-            }
-            // deepest hit first
-            v = nodeLo(sc, ft, wb, (uint32_t)chain[n - 1], wp.slots);
-            if (link == kChildMiss) {
-                const float4 a3 = wb.nodeA[4u * (size_t)chain[n - 1] + 3];
-                v = v + cv * mk3(a3.x, a3.y, a3.z);
-            }
-            for (int k = n - 2; k >= 0; k--) {
-                const float4 a3 = wb.nodeA[4u * (size_t)chain[k] + 3];
-                v = nodeLo(sc, ft, wb, (uint32_t)chain[k], wp.slots) + v * mk3(a3.x, a3.y, a3.z);
-            }
-        }
-        L = L + v;
+    const int32_t head = wb.pathHead[path];
+    if (head == kPathMiss)
+        return ft.envMap ? ld3(wb.pathEnv + 3u * path) : mk3(0.0f);
+    int32_t chain[kMaxDepth + 1];
+    int n = 0;
+    int32_t cur = head, link = kChildNone;
+    f3 cv = mk3(0.0f);
+    while (n <= kMaxDepth) {
+        chain[n++] = cur;
+        const NodeB nb = wb.nodeB[cur];
+        link = nb.child;
+        cv = ld3(nb.cv);
+        if (link < 0)
+            break;
+        cur = link;
     }
-    const f3 c = L / (float)wp.R;
-    const uint32_t slot = wp.slotBegin + s;
-    const size_t idx = fr.packed ? (size_t)slot : ((size_t)(fr.height - 1 - py) * fr.width + px);
-    out[3 * idx + 0] = c.x;
-    out[3 * idx + 1] = c.y;
-    out[3 * idx + 2] = c.z;
+    // deepest hit first
+    f3 v = nodeLo(sc, ft, wb, (uint32_t)chain[n - 1], wp.slots);
+    if (link == kChildMiss) {
+        const float4 a3 = wb.nodeA[4u * (size_t)chain[n - 1] + 3];
+        v = v + cv * mk3(a3.x, a3.y, a3.z);
+    }
+    for (int k = n - 2; k >= 0; k--) {
+        const float4 a3 = wb.nodeA[4u * (size_t)chain[k] + 3];
+        v = nodeLo(sc, ft, wb, (uint32_t)chain[k], wp.slots) + v * mk3(a3.x, a3.y, a3.z);
+    }
+    return v;
+}
+
+// One lane per camera ray evaluates its chain (the chains of a pixel sit all over the node
+// pool, so their latencies overlap instead of queueing up in one lane); the first lane of
+// each pixel then adds the pixel's values in ray order, exactly as renderRays does.
+__global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp,
+    const WfBuffers wb, float* __restrict__ out)
+{
+    __shared__ float vals[256 * 3];
+    const uint32_t perRound = wp.R < 256u ? wp.R : 256u; // rays of one pixel handled side by side
+    const uint32_t pixelsPerBlock = 256u / perRound;
+    const uint32_t pl = threadIdx.x / perRound, j = threadIdx.x % perRound;
+    const uint32_t s = blockIdx.x * pixelsPerBlock + pl;
+    int px = 0, py = 0;
+    const bool valid = pl < pixelsPerBlock && s < wp.nSlots && slotToPixel(fr, wp.slotBegin + s, px, py);
+    f3 L = mk3(0.0f);
+    for (uint32_t base = 0; base < wp.R; base += perRound) {
+        const uint32_t i = base + j;
+        f3 v = mk3(0.0f);
+        if (valid && i < wp.R)
+            v = pathValue(sc, ft, wp, wb, s * wp.R + i);
+        vals[3u * threadIdx.x + 0] = v.x;
+        vals[3u * threadIdx.x + 1] = v.y;
+        vals[3u * threadIdx.x + 2] = v.z;
+        __syncthreads();
+        if (valid && j == 0) {
+            const uint32_t n = (wp.R - base < perRound) ? wp.R - base : perRound;
+            for (uint32_t k = 0; k < n; k++)
+                L = L + ld3(vals + 3u * (threadIdx.x + k));
+        }
+        __syncthreads();
+    }
+    if (valid && j == 0) {
+        const f3 c = L / (float)wp.R;
+        const uint32_t slot = wp.slotBegin + s;
+        const size_t idx = fr.packed ? (size_t)slot : ((size_t)(fr.height - 1 - py) * fr.width + px);
+        out[3 * idx + 0] = c.x;
+        out[3 * idx + 1] = c.y;
+        out[3 * idx + 2] = c.z;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -614,7 +635,8 @@ hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlock
     if (marks)
         (void)hipEventRecord(marks[2], stream);
     hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
-    hipLaunchKernelGGL(combineKernel, dim3(pb), dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
+    const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
+    hipLaunchKernelGGL(combineKernel, dim3((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock), dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
     return hipGetLastError();
 }
 
