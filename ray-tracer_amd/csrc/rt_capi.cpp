@@ -43,6 +43,7 @@ struct rt_ctx {
     std::string error;
     // device buffers
     uint4* dPairs = nullptr;
+    uint32_t numPairs = 0; // pair records in dPairs
     float4* dTris = nullptr;
     float4* dAttrs = nullptr;
     DevMaterial* dMats = nullptr;
@@ -549,6 +550,33 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
         if (bld.maxDepth + 1 <= (uint32_t)kMaxStack) {
             ownTree = true;
             maxLevel = bld.maxDepth + 1;
+            // breadth-first order: the records every ray starts with sit next to each other
+            if ((rootRef & kLeafFlag) == 0) {
+                const uint32_t nPairs = static_cast<uint32_t>(pairs.size() / 2);
+                std::vector<uint32_t> order, newIndex(nPairs, 0);
+                order.reserve(nPairs);
+                order.push_back(rootRef);
+                for (size_t h = 0; h < order.size(); h++) {
+                    const uint4 w1 = pairs[2 * static_cast<size_t>(order[h]) + 1];
+                    if ((w1.z & kLeafFlag) == 0)
+                        order.push_back(w1.z);
+                    if ((w1.w & kLeafFlag) == 0)
+                        order.push_back(w1.w);
+                }
+                for (uint32_t k = 0; k < order.size(); k++)
+                    newIndex[order[k]] = k;
+                std::vector<uint4> sorted(pairs.size());
+                for (uint32_t k = 0; k < order.size(); k++) {
+                    uint4 w0 = pairs[2 * static_cast<size_t>(order[k])], w1 = pairs[2 * static_cast<size_t>(order[k]) + 1];
+                    if ((w1.z & kLeafFlag) == 0)
+                        w1.z = newIndex[w1.z];
+                    if ((w1.w & kLeafFlag) == 0)
+                        w1.w = newIndex[w1.w];
+                    sorted[2 * static_cast<size_t>(k)] = w0, sorted[2 * static_cast<size_t>(k) + 1] = w1;
+                }
+                pairs.swap(sorted);
+                rootRef = 0;
+            }
         } else {
             pairs.clear();
         }
@@ -631,6 +659,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, uploadVec(&ctx->dPairs, pairs));
+    ctx->numPairs = static_cast<uint32_t>(pairs.size() / 2);
     HIP_TRY(ctx, uploadVec(&ctx->dTris, tris));
     HIP_TRY(ctx, uploadVec(&ctx->dAttrs, attrs));
     HIP_TRY(ctx, uploadVec(&ctx->dMats, mats));
@@ -818,7 +847,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     fr.packed = (nShard == 1) ? 0 : 1;
 
     const int blockThreads = 256;
-    const uint32_t stackEntries = std::max<uint32_t>(ctx->numLevels, 2);
+    const uint32_t stackEntries = std::max<uint32_t>(ctx->numLevels, 2) + 1; // one more for the bottom marker
     const size_t lds = static_cast<size_t>(stackEntries) * blockThreads * 4;
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, sizeof(DevCounters), stream));
@@ -882,11 +911,14 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         if (wp.R == 0 || wp.R > 65535u)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
         const bool dof = F.enableDepthOfField != 0;
-        int pathPerCU = ctx->blocksPerCU, shadowPerCU = ctx->blocksPerCU;
-        if (pathPerCU <= 0) {
-            HIP_TRY(ctx, wavefrontOccupancy(collect, blockThreads, lds, &pathPerCU, &shadowPerCU));
-            pathPerCU = std::max(1, std::min(pathPerCU, 8));
-            shadowPerCU = std::max(1, std::min(shadowPerCU, 8));
+        int pathPerCU = 0, shadowPerCU = 0;
+        HIP_TRY(ctx, wavefrontOccupancy(collect, blockThreads, lds, &pathPerCU, &shadowPerCU));
+        if (pathPerCU < 1 || shadowPerCU < 1)
+            return fail(ctx, RT_ERR_DEVICE, "render: the traversing kernels do not fit a compute unit (%zu B of LDS)", lds);
+        pathPerCU = std::min(pathPerCU, 8), shadowPerCU = std::min(shadowPerCU, 8);
+        if (ctx->blocksPerCU > 0) { // experiments: fewer blocks than fit
+            pathPerCU = std::min(pathPerCU, ctx->blocksPerCU);
+            shadowPerCU = std::min(shadowPerCU, ctx->blocksPerCU);
         }
         // every wavefront of the path kernel may leave part of its last block of node slots unused
         const uint64_t nodeSlack = static_cast<uint64_t>(ctx->numCU) * pathPerCU * (blockThreads / 64) * kNodeBlock;
@@ -975,6 +1007,13 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
             const double li = k ? double(c.sInner) : double(c.inner - c.sInner), lt = k ? double(c.sTris) : double(c.tris - c.sTris);
             fprintf(stderr, "[rt_amd] %s: inner wave-iters %.0f (%.1f lanes busy), leaf wave-iters %.0f (%.1f lanes testing), run() calls %.0f\n",
                 names[k], wi, wi > 0 ? li / wi : 0.0, wl, wl > 0 ? lt / wl : 0.0, wr);
+            if (c.cycles[k][3])
+                fprintf(stderr, "[rt_amd] %s: of a wave's clocks: inner block %.3f (%.0f per iteration), leaf block %.3f (%.0f per iteration), rest of run() %.3f, outside run() %.3f\n",
+                    names[k], double(c.cycles[k][0]) / c.cycles[k][3], wi > 0 ? c.cycles[k][0] / wi : 0.0, double(c.cycles[k][1]) / c.cycles[k][3],
+                    wl > 0 ? c.cycles[k][1] / wl : 0.0, (double(c.cycles[k][2]) - c.cycles[k][0] - c.cycles[k][1]) / c.cycles[k][3],
+                    1.0 - double(c.cycles[k][2]) / c.cycles[k][3]);
+            fprintf(stderr, "[rt_amd] %s: share of inner steps at pair records below 1024 / 2048 / 4096: %.3f %.3f %.3f (%u levels)\n", names[k],
+                li > 0 ? c.topHits[k][0] / li : 0.0, li > 0 ? c.topHits[k][1] / li : 0.0, li > 0 ? c.topHits[k][2] / li : 0.0, ctx->numLevels);
         }
     }
     if (stats) {
@@ -1118,7 +1157,7 @@ int rt_intersect_batch(rt_ctx* ctx, rt_ray* rays, uint32_t n, rt_hit* hits)
     if (e == hipSuccess) {
         const DevFeat ft = makeFeat(ctx->features);
         const int blockThreads = 256;
-        const size_t lds = static_cast<size_t>(std::max<uint32_t>(ctx->numLevels, 2)) * blockThreads * 4;
+        const size_t lds = static_cast<size_t>(std::max<uint32_t>(ctx->numLevels, 2) + 1) * blockThreads * 4; // + the bottom marker
         e = launchIntersect(blockThreads, lds, nullptr, ctx->scene, ft, dRays, dHits, n);
     }
     if (e == hipSuccess)

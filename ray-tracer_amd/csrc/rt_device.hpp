@@ -171,6 +171,8 @@ struct DevCounters {
     // counting launches only: iterations of the traversal loop summed over all 64 lanes of
     // every wave (divide by 64 for wave iterations), [0] inner [1] leaf [2] calls of run()
     unsigned long long loopIters[2][3]; // [0] path kernel, [1] shadow kernel
+    unsigned long long topHits[2][3];   // inner steps at pair records below 1024 / 2048 / 4096
+    unsigned long long cycles[2][4];    // shader clocks summed over waves: inner block, leaf block, run(), whole kernel
 };
 
 // ----------------------------------------------------------------------------
@@ -409,9 +411,8 @@ __device__ __forceinline__ bool triangleTest(const TriRec& r, f3 o, f3 d, float 
 
 // The same test reading the record in two steps: the 16-B plane first, the
 // remaining 80 B only for rays whose plane hit lies inside [0, tmax].
-__device__ __forceinline__ bool triangleTestLazy(const float4* __restrict__ tris, uint32_t i, f3 o, f3 d, float tmax, float& tOut)
+__device__ __forceinline__ bool triangleTestLazy(const float4* __restrict__ p4, f3 o, f3 d, float tmax, float& tOut)
 {
-    const float4* p4 = tris + 6u * i;
     const float4 a = p4[0];
     const f3 n = { a.x, a.y, a.z };
     const float t = (a.w - dot(o, n)) / dot(d, n);

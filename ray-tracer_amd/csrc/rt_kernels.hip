@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
     Frame frames[kMaxDepth + 1];
     GlossyFrame gframes[(V & V_GLOSSY) ? (kMaxDepth + 1) : 1];
 
-    const Tracer<(V & V_STATS) != 0> tracer { sc, ft.accel, stackMem + threadIdx.x };
+    const Tracer<(V & V_STATS) != 0> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const Shader<V> shader { sc, cam, ft, fr, tracer, out, frames, gframes };
 
     Lane L;
@@ -402,9 +402,11 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
     L.nrays = 0;
     L.r.nInner = L.r.nTris = 0;
     L.r.itInner = L.r.itLeaf = L.r.itRuns = 0;
+    L.r.topHits[0] = L.r.topHits[1] = L.r.topHits[2] = 0;
+    L.r.cycInner = L.r.cycLeaf = L.r.cycRun = 0;
     L.r.cur = kRefNone;
     L.r.pend = 0u;
-    L.r.sp = 0;
+    L.r.top = tracer.stk;
     L.r.active = false;
     L.depth = 0;
 
@@ -502,12 +504,12 @@ __global__ __launch_bounds__(256) void intersectKernel(const DevScene sc, const 
     rt_hit* __restrict__ hits, uint32_t n)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<false> tracer { sc, ft.accel, stackMem + threadIdx.x };
+    const Tracer<false> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     RayState L;
     L.cur = kRefNone;
     L.pend = 0u;
-    L.sp = 0;
+    L.top = tracer.stk;
     L.active = false;
     L.nInner = L.nTris = 0;
     if (i < n) {

@@ -7,6 +7,10 @@
 
 #include "rt_device.hpp"
 
+#ifndef RT_INNER_STEPS
+#define RT_INNER_STEPS 3 // sibling pairs a lane may visit between two votes of the traversal loop
+#endif
+
 namespace rt {
 
 constexpr uint32_t kBlockThreads = 256;
@@ -17,24 +21,31 @@ constexpr int kHitNone = -1;
 constexpr float kFltMax = 3.402823466e+38f;
 constexpr float kTwoPi = 6.28318530717958647692528676655900576f;
 
+typedef __attribute__((address_space(3))) uint32_t* LdsWords;
+
 struct RayState {
     f3 o, d;
-    // Slab arithmetic against the quantised boxes: plane distance t = q * A + B per
-    // axis, B widened by the rounding bound of that expression (Bn for the plane the
-    // ray enters through, Bf for the one it leaves through); rot selects which half
-    // of a box dword is the entering plane (0 or 16 per axis, 5 bits each).
+    // Slab arithmetic against the quantised boxes.  A plane q (16-bit grid position)
+    // is turned into the float 2^23 + q by gluing the exponent byte 0x4B on top of its
+    // two bytes, so its distance along the ray is one fma: t = (2^23 + q) * A + B with
+    // B = (gridMin - o) / d - 2^23 * A, widened by the rounding bound of that
+    // expression (Bn for the plane the ray enters through, Bf for the one it leaves
+    // through).  selN / selF are the byte selectors that pick the entering / leaving
+    // half of a box dword (lo | hi << 16) for this ray's direction signs.
     f3 A, Bn, Bf;
-    uint32_t rot;
+    uint32_t selNx, selNy, selNz, selFx, selFy, selFz;
     float tmax, slen; // current closest t; the ray's original length (shadow rays)
     int hitPrim;      // primitive index, kHitNone, or -2 - sphere index
     int kind;
     uint32_t cur;     // node reference to visit next, kRefNone when the stack has run dry
     uint32_t pend;    // parked leaf reference whose primitives are still to be tested, 0 = none
-    uint32_t li, le;  // next primitive of the parked leaf and its end
-    int sp;
+    uint32_t li, le;  // next primitive of the parked leaf and its end, as indices into the float4 array (6 per primitive)
+    LdsWords top;     // first free entry of this lane's traversal stack
     bool active;      // still inside the traversal loop
     uint32_t nInner, nTris;
     uint32_t itInner, itLeaf, itRuns; // counting builds: loop iterations this lane sat through
+    uint32_t topHits[3];              // counting builds: inner steps at pair records below 1024 / 2048 / 4096
+    unsigned long long cycInner, cycLeaf, cycRun; // counting builds: shader clocks spent in the two blocks and in run() as a whole
 };
 
 __device__ __forceinline__ f3 rcp3(f3 d)
@@ -46,20 +57,20 @@ template <bool STATS>
 struct Tracer {
     const DevScene& sc;
     int accel;
-    uint32_t* stk; // this lane's column of the LDS stack
+    LdsWords stk; // this lane's column of the LDS stack
     static constexpr uint32_t stride = kBlockThreads; // every traversing kernel runs 256-thread blocks
 
+    // The bottom entry of every stack holds kRefNone (begin()), so a pop needs no
+    // emptiness check: the last pop of a traversal returns "no node".
     __device__ __forceinline__ uint32_t pop(RayState& r) const
     {
-        if (r.sp == 0)
-            return kRefNone;
-        r.sp--;
-        return stk[r.sp * stride];
+        r.top -= stride;
+        return *r.top;
     }
     __device__ __forceinline__ void push(RayState& r, uint32_t ref) const
     {
-        stk[r.sp * stride] = ref;
-        r.sp++;
+        *r.top = ref;
+        r.top += stride;
     }
 
     __device__ __forceinline__ void begin(RayState& r, f3 o, f3 d, float tmax, int kind) const
@@ -70,7 +81,8 @@ struct Tracer {
         r.slen = tmax;
         r.kind = kind;
         r.hitPrim = kHitNone;
-        r.sp = 0;
+        r.top = stk;
+        push(r, kRefNone);
         r.cur = kRefNone;
         r.pend = 0u;
         r.active = false;
@@ -88,19 +100,33 @@ struct Tracer {
     __device__ __forceinline__ void enter(RayState& r, f3 inv) const
     {
         setCur(r, sc.rootRef);
-        // t(q) = ((gridMin + q*cell) - o) * inv = q*A + B.  Rounding bound of the
-        // fused form: (|q*A| + |B|) * 2^-22 for the inputs plus half an ulp of
-        // the result; (extent*|inv| + |B|) * 2^-20 covers it with room to spare.
+        // t(q) = ((gridMin + q*cell) - o) * inv = q*A + B.  Rounding bound of the fused
+        // form: (|q*A| + |B|) * 2^-22 for the inputs plus half an ulp of the result;
+        // (extent*|inv| + |B|) * 2^-20 covers it with room to spare.  Moving 2^23 * A
+        // from the product into B costs one more rounding, of at most half an ulp of
+        // 2^23 * |A| + |B|, i.e. |A| / 2 on top of what the first term already covers.
         const f3 gmin = { sc.gridMin[0], sc.gridMin[1], sc.gridMin[2] };
         const f3 cell = { sc.gridCell[0], sc.gridCell[1], sc.gridCell[2] };
-        r.A = cell * inv;
+        f3 A = cell * inv;
         const f3 B = (gmin - r.o) * inv;
         const float k = 9.5367431640625e-7f; // 2^-20
-        const f3 err = { (65535.0f * fabsf(r.A.x) + fabsf(B.x)) * k, (65535.0f * fabsf(r.A.y) + fabsf(B.y)) * k,
-            (65535.0f * fabsf(r.A.z) + fabsf(B.z)) * k };
-        r.Bn = B - err;
-        r.Bf = B + err;
-        r.rot = (inv.x < 0.0f ? 16u : 0u) | (inv.y < 0.0f ? 16u << 5 : 0u) | (inv.z < 0.0f ? 16u << 10 : 0u);
+        const f3 err = { (65535.0f * fabsf(A.x) + fabsf(B.x)) * k + 0.5005f * fabsf(A.x),
+            (65535.0f * fabsf(A.y) + fabsf(B.y)) * k + 0.5005f * fabsf(A.y),
+            (65535.0f * fabsf(A.z) + fabsf(B.z)) * k + 0.5005f * fabsf(A.z) };
+        const f3 C = 8388608.0f * A;
+        f3 Bn = (B - err) - C, Bf = (B + err) - C;
+        // An axis the ray (almost) does not move along: its slab places no bound.  That is
+        // what the reference's box routine does for a zero component, and for a huge 1/d it
+        // only means a few more boxes visited.
+        const bool okx = fabsf(A.x) < 1.0e30f && fabsf(B.x) < 1.0e30f, oky = fabsf(A.y) < 1.0e30f && fabsf(B.y) < 1.0e30f,
+                   okz = fabsf(A.z) < 1.0e30f && fabsf(B.z) < 1.0e30f;
+        r.A = { okx ? A.x : 0.0f, oky ? A.y : 0.0f, okz ? A.z : 0.0f };
+        r.Bn = { okx ? Bn.x : -kFltMax, oky ? Bn.y : -kFltMax, okz ? Bn.z : -kFltMax };
+        r.Bf = { okx ? Bf.x : kFltMax, oky ? Bf.y : kFltMax, okz ? Bf.z : kFltMax };
+        const uint32_t selLo = 0x030c0504u, selHi = 0x030c0706u; // {0x4B, 0x00, w.b1, w.b0} / {0x4B, 0x00, w.b3, w.b2}
+        r.selNx = inv.x < 0.0f ? selHi : selLo, r.selFx = inv.x < 0.0f ? selLo : selHi;
+        r.selNy = inv.y < 0.0f ? selHi : selLo, r.selFy = inv.y < 0.0f ? selLo : selHi;
+        r.selNz = inv.z < 0.0f ? selHi : selLo, r.selFz = inv.z < 0.0f ? selLo : selHi;
     }
 
     // One BVHInterface::intersect call begins (src/bvh.cpp:337-358).  The root
@@ -136,17 +162,17 @@ struct Tracer {
     }
 
     // Conservative slab test against one quantised child box (three dwords, lo | hi << 16
-    // per axis).  Rotating a dword by the ray's per-axis amount puts the plane the ray
-    // enters through into the low half, so no min/max per axis is needed.  A NaN slab
-    // (zero direction component) drops out of the max/min, i.e. that axis is ignored,
-    // which is what the reference's box routine does for it.
-    __device__ __forceinline__ bool qboxTest(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t rx, uint32_t ry, uint32_t rz,
-        const RayState& r, float& entry) const
+    // per axis).  One byte permute per plane picks the half the ray enters (leaves)
+    // through and makes it a float; no min/max per axis is needed.
+    __device__ __forceinline__ bool qboxTest(uint32_t wx, uint32_t wy, uint32_t wz, const RayState& r, float& entry) const
     {
-        const uint32_t qx = __builtin_rotateleft32(wx, rx), qy = __builtin_rotateleft32(wy, ry), qz = __builtin_rotateleft32(wz, rz);
-        const float nx = __builtin_fmaf((float)(qx & 0xffffu), r.A.x, r.Bn.x), fx = __builtin_fmaf((float)(qx >> 16), r.A.x, r.Bf.x);
-        const float ny = __builtin_fmaf((float)(qy & 0xffffu), r.A.y, r.Bn.y), fy = __builtin_fmaf((float)(qy >> 16), r.A.y, r.Bf.y);
-        const float nz = __builtin_fmaf((float)(qz & 0xffffu), r.A.z, r.Bn.z), fz = __builtin_fmaf((float)(qz >> 16), r.A.z, r.Bf.z);
+        const uint32_t K = 0x4b000000u;
+        const float nx = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(wx, K, r.selNx)), r.A.x, r.Bn.x);
+        const float fx = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(wx, K, r.selFx)), r.A.x, r.Bf.x);
+        const float ny = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(wy, K, r.selNy)), r.A.y, r.Bn.y);
+        const float fy = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(wy, K, r.selFy)), r.A.y, r.Bf.y);
+        const float nz = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(wz, K, r.selNz)), r.A.z, r.Bn.z);
+        const float fz = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(wz, K, r.selFz)), r.A.z, r.Bf.z);
         const float tIn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
         const float tOut = fminf(fminf(fx, fy), fz);
         entry = tIn;
@@ -164,10 +190,11 @@ struct Tracer {
     // spot: it parks the leaf in `pend` and goes on down the tree (pops the next
     // node), so that most lanes can still take inner steps while they already
     // hold triangle work; only with a second leaf in hand does a lane have to
-    // wait.  Per iteration the wave runs ONE of the two code blocks -- an inner
-    // step (one sibling pair) for every lane that has a node, or one triangle
-    // test for every lane that has a parked leaf -- whichever more lanes are
-    // ready for (ballot vote).  Along one ray the near child still goes first
+    // wait.  Per iteration the wave runs ONE of the two code blocks -- up to
+    // RT_INNER_STEPS inner steps (one sibling pair each) for every lane that has
+    // a node, or one triangle test for every lane that has a parked leaf --
+    // whichever more lanes are ready for (ballot vote; a few steps per vote
+    // spread the cost of the vote itself).  Along one ray the near child still goes first
     // and the primitives of a leaf are tested in order; a parked leaf only sees
     // its ray's t a few steps later than it would have, which changes how many
     // boxes are culled but not which hit is the closest.
@@ -177,21 +204,25 @@ struct Tracer {
     __device__ __forceinline__ void run(RayState& r, int knobs) const
     {
         const int minActive = knobs & 0xff, voteScale = (knobs >> 8) & 0xff, voteBias = (knobs >> 16) & 0xff;
-        const uint32_t rx = r.rot & 31u, ry = (r.rot >> 5) & 31u, rz = (r.rot >> 10) & 31u;
-        if (STATS)
+        long long tRun = 0;
+        if (STATS) {
             r.itRuns++;
+            tRun = clock64();
+        }
         for (;;) {
             if ((int32_t)r.cur < 0 && r.pend == 0u) { // a leaf and a free slot: park it, take the next node
-                const uint32_t count = (r.cur >> 27) & 15u;
+                const uint32_t count = (r.cur >> 27) & 15u, first = r.cur & kLeafOffsetMask;
                 r.pend = count ? r.cur : 0u; // an empty leaf is dropped here
-                r.li = r.cur & kLeafOffsetMask;
-                r.le = r.li + count;
+                r.li = (first << 2) + (first << 1);
+                r.le = r.li + (count << 2) + (count << 1);
                 r.cur = pop(r);
             }
+            // every lane with a ray in flight can take an inner step, a triangle test, or both:
+            // a lane whose node is a second leaf holds a parked one
             const bool canInner = r.cur < kRefNone; // leaf refs have the top bit set, kRefNone is the largest inner value
             const bool canLeaf = r.pend != 0u;
-            const int nInner = __popcll(__ballot(canInner)), nLeaf = __popcll(__ballot(canLeaf));
-            const int alive = __popcll(__ballot(canLeaf || r.cur != kRefNone));
+            const unsigned long long mInner = __ballot(canInner), mLeaf = __ballot(canLeaf);
+            const int nInner = __popcll(mInner), nLeaf = __popcll(mLeaf), alive = __popcll(mInner | mLeaf);
             if (alive == 0 || alive < minActive)
                 break;
             // vote: triangles when the lanes holding a leaf outnumber (scaled, biased) those with a node
@@ -200,31 +231,46 @@ struct Tracer {
                 leafMode = true;
             if (nLeaf == 0)
                 leafMode = false;
+            long long t0 = 0;
+            if (STATS)
+                t0 = clock64();
             if (!leafMode) {
-                if (STATS)
-                    r.itInner++;
                 if (canInner)
-                    innerStep(r, rx, ry, rz);
+                    innerStep(r);
+#pragma unroll
+                for (int k = 1; k < RT_INNER_STEPS; k++)
+                    if (r.cur < kRefNone)
+                        innerStep(r);
+                if (STATS) {
+                    r.itInner++;
+                    r.cycInner += (unsigned long long)(clock64() - t0);
+                }
             } else {
-                if (STATS)
-                    r.itLeaf++;
                 if (canLeaf)
                     leafStep(r);
+                if (STATS) {
+                    r.itLeaf++;
+                    r.cycLeaf += (unsigned long long)(clock64() - t0);
+                }
             }
         }
+        if (STATS)
+            r.cycRun += (unsigned long long)(clock64() - tRun);
         r.active = r.pend != 0u || r.cur != kRefNone;
     }
 
     // One sibling-pair record (32 B): test both children, descend into the nearer.
-    __device__ __forceinline__ void innerStep(RayState& r, uint32_t rx, uint32_t ry, uint32_t rz) const
+    __device__ __forceinline__ void innerStep(RayState& r) const
     {
         const uint4* p = sc.pairs + 2u * r.cur;
         const uint4 w0 = p[0], w1 = p[1];
-        if (STATS)
+        if (STATS) {
             r.nInner++;
+            r.topHits[0] += r.cur < 1024u, r.topHits[1] += r.cur < 2048u, r.topHits[2] += r.cur < 4096u;
+        }
         float eL, eR;
-        const bool hL = qboxTest(w0.x, w0.y, w0.z, rx, ry, rz, r, eL);
-        const bool hR = qboxTest(w0.w, w1.x, w1.y, rx, ry, rz, r, eR);
+        const bool hL = qboxTest(w0.x, w0.y, w0.z, r, eL);
+        const bool hR = qboxTest(w0.w, w1.x, w1.y, r, eR);
         // nearer child first; on a tie the right child, as in src/bvh.cpp:301-307
         const bool takeLeft = hL && (!hR || eL < eR);
         const uint32_t nearRef = takeLeft ? w1.z : w1.w, farRef = takeLeft ? w1.w : w1.z;
@@ -239,9 +285,9 @@ struct Tracer {
         float t;
         if (STATS)
             r.nTris++;
-        if (triangleTestLazy(sc.tris, r.li, r.o, r.d, r.tmax, t)) {
+        if (triangleTestLazy(sc.tris + r.li, r.o, r.d, r.tmax, t)) {
             r.tmax = t;
-            r.hitPrim = (int)r.li;
+            r.hitPrim = (int)(r.li / 6u);
             // Binary visibility only asks whether the closest hit lies more
             // than 1e-4 before the target (src/light.cpp:101-104); any hit
             // that does settles it, the closest one is at least as near.
@@ -251,7 +297,7 @@ struct Tracer {
                 return;
             }
         }
-        r.li++;
+        r.li += 6u;
         if (r.li >= r.le)
             r.pend = 0u;
     }

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
 {
     __shared__ uint32_t waveCount[4];
     __shared__ uint32_t blockBase;
-    const Tracer<false> tracer { sc, ft.accel, nullptr };
+    const Tracer<false> tracer { sc, ft.accel, (LdsWords)0 };
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t total = wp.nSlots * wp.R;
     const uint32_t path = blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFe
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x };
+    const Tracer<STATS> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = ctr->camQueued;
 
@@ -176,12 +176,15 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFe
     r.active = false;
     r.cur = kRefNone;
     r.pend = 0u;
-    r.sp = 0;
+    r.top = tracer.stk;
     r.nInner = r.nTris = 0;
     r.itInner = r.itLeaf = r.itRuns = 0;
+    r.topHits[0] = r.topHits[1] = r.topHits[2] = 0;
+    r.cycInner = r.cycLeaf = r.cycRun = 0;
+    const long long tKernel = STATS ? clock64() : 0;
     uint32_t path = 0, item = 0, nrays = 0, made = 0;
     __shared__ uint32_t nodeBlkAll[4][2]; // per wave: next free slot and end of its block of node slots
-    volatile uint32_t* nodeBlk = nodeBlkAll[threadIdx.x >> 6];
+    volatile __attribute__((address_space(3))) uint32_t* nodeBlk = (volatile __attribute__((address_space(3))) uint32_t*)nodeBlkAll[threadIdx.x >> 6];
     if (lane == 0)
         nodeBlk[0] = nodeBlk[1] = 0u;
     int depth = 0, prev = -1, count = 0;
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFe
     const unsigned long long srays = ft.shadows ? waveSum(made) * wp.slots : 0ull;
     const unsigned long long rs = waveSum(nrays), ni = waveSum(r.nInner), nt = waveSum(r.nTris);
     const unsigned long long ii = waveSum(r.itInner), il = waveSum(r.itLeaf), ir = waveSum(r.itRuns);
+    const unsigned long long th[3] = { waveSum(r.topHits[0]), waveSum(r.topHits[1]), waveSum(r.topHits[2]) };
     if (lane == 0) {
         // reflection rays counted here; every camera ray of a real pixel is one intersect call, traced or not
         atomicAdd(&ctr->rays, rs + srays + ((blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)wp.validPaths : 0ull));
@@ -316,6 +320,12 @@ __global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFe
             atomicAdd(&ctr->loopIters[0][0], ii);
             atomicAdd(&ctr->loopIters[0][1], il);
             atomicAdd(&ctr->loopIters[0][2], ir);
+            for (int k = 0; k < 3; k++)
+                atomicAdd(&ctr->topHits[0][k], th[k]);
+            atomicAdd(&ctr->cycles[0][0], r.cycInner);
+            atomicAdd(&ctr->cycles[0][1], r.cycLeaf);
+            atomicAdd(&ctr->cycles[0][2], r.cycRun);
+            atomicAdd(&ctr->cycles[0][3], (unsigned long long)(clock64() - tKernel));
         }
     }
 }
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<STATS> tracer { sc, ft.accel, stackMem + threadIdx.x };
+    const Tracer<STATS> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nNodesAll = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
     const uint32_t total = ft.shadows ? nNodesAll * wp.slots : 0u; // shadows off: no ray at all (src/light.cpp:270-272)
@@ -428,9 +438,12 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     r.active = false;
     r.cur = kRefNone;
     r.pend = 0u;
-    r.sp = 0;
+    r.top = tracer.stk;
     r.nInner = r.nTris = 0;
     r.itInner = r.itLeaf = r.itRuns = 0;
+    r.topHits[0] = r.topHits[1] = r.topHits[2] = 0;
+    r.cycInner = r.cycLeaf = r.cycRun = 0;
+    const long long tKernel = STATS ? clock64() : 0;
     uint32_t item = 0;
     bool have = false, dead = false;
     WaveQueue q;
@@ -465,6 +478,7 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
 
     const unsigned long long ni = waveSum(r.nInner), nt = waveSum(r.nTris);
     const unsigned long long ii = waveSum(r.itInner), il = waveSum(r.itLeaf), ir = waveSum(r.itRuns);
+    const unsigned long long th[3] = { waveSum(r.topHits[0]), waveSum(r.topHits[1]), waveSum(r.topHits[2]) };
     if (lane == 0) {
         if (STATS) {
             atomicAdd(&ctr->inner, ni);
@@ -474,6 +488,12 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
             atomicAdd(&ctr->loopIters[1][0], ii);
             atomicAdd(&ctr->loopIters[1][1], il);
             atomicAdd(&ctr->loopIters[1][2], ir);
+            for (int k = 0; k < 3; k++)
+                atomicAdd(&ctr->topHits[1][k], th[k]);
+            atomicAdd(&ctr->cycles[1][0], r.cycInner);
+            atomicAdd(&ctr->cycles[1][1], r.cycLeaf);
+            atomicAdd(&ctr->cycles[1][2], r.cycRun);
+            atomicAdd(&ctr->cycles[1][3], (unsigned long long)(clock64() - tKernel));
         }
     }
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Sweep of queue chunk sizes on the bench workload (GPU box).
+# Sweep of refill thresholds on the bench workload (GPU box).
 source tools/ab.sh
-for c in 64 128 256 512; do run "chunkPath=$c" RT_AMD_CHUNK_PATH=$c || exit 1; done
-for c in 64 128 256 512 1024; do run "chunkShadow=$c" RT_AMD_CHUNK_SHADOW=$c || exit 1; done
+for c in 24 32 40 48 56; do run "minActiveShadow=$c" RT_AMD_MIN_ACTIVE_SHADOW=$c || exit 1; done
+for c in 16 24 32 40 48; do run "minActive=$c" RT_AMD_MIN_ACTIVE=$c RT_AMD_MIN_ACTIVE_SHADOW=48 || exit 1; done
