@@ -359,67 +359,96 @@ __global__ void prefixKernel(const DevFrame fr, const WfParams wp, const WfBuffe
 //    (c) shade the visible samples, one lane per (hit, sample) again.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp,
-    const WfBuffers wb, DevCounters* __restrict__ ctr)
+    const WfBuffers wb, DevCounters* __restrict__ ctr, const rt_light* __restrict__ lightsGlobal)
 {
+    // `lights` is sc.lights again, seen through the constant address space: nothing this kernel
+    // stores changes a light, and only so are they read through the scalar cache
+    typedef __attribute__((address_space(4))) const uint32_t* ConstWords;
+    const ConstWords lights = (ConstWords)(uintptr_t)lightsGlobal;
+    constexpr uint32_t kLightWords = sizeof(rt_light) / 4;
     const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
     const uint32_t total = nNodes * wp.slots; // host guarantees maxNodes * slots < 2^32
     for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
         const uint32_t item = base + threadIdx.x;
+        // which light and which of its samples; draws consumed by the lights before it
+        // (the loop runs the same for every lane, so the lights are read through the scalar cache)
+        int l = -1;
+        uint32_t slot = 0, drawPrefix = 0, perSample = 0;
+        uint32_t node = 0, path = 0, depth = 0;
+        bool live = false;
         if (item < total) {
-            const uint32_t node = item / wp.slots;
-            uint32_t slot = item % wp.slots;
-            // which light and which of its samples; draws consumed by the lights before it
-            int l = 0;
-            uint32_t drawPrefix = 0, perSample = 0;
-            for (; l < sc.nLights; l++) {
-                const int type = sc.lights[l].type;
+            node = item / wp.slots;
+            const uint32_t sl = item % wp.slots;
+            uint32_t first = 0, draws = 0;
+            for (int k = 0; k < sc.nLights; k++) {
+                const int type = (int)lights[k * kLightWords]; // rt_light::type
                 const uint32_t n = (type == 0) ? 1u : ft.shadowSamples;
-                perSample = (type == 0) ? 0u : (type == 1 ? 1u : 2u);
-                if (slot < n)
-                    break;
-                slot -= n;
-                drawPrefix += n * perSample;
+                const uint32_t per = (type == 0) ? 0u : (type == 1 ? 1u : 2u);
+                if (l < 0 && sl < first + n)
+                    l = k, slot = sl - first, drawPrefix = draws, perSample = per;
+                first += n;
+                draws += n * per;
             }
-            const NodeB nb = wb.nodeB[node];
-            float4* sr = wb.srays + 3u * (size_t)item;
-            if (nb.path == kDeadNode) { // a slot no hit was written to: no ray, no light
+            const uint2 pd = *reinterpret_cast<const uint2*>(&wb.nodeB[node]); // path, depth
+            path = pd.x, depth = pd.y;
+            live = l >= 0 && path != kDeadNode;
+            if (!live) { // a slot no hit was written to: no ray, no light
+                float4* sr = wb.srays + 3u * (size_t)item;
                 sr[0] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
                 sr[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 wb.svis[item] = 0;
-                continue;
             }
-            const float4 a0 = wb.nodeA[4u * (size_t)node];
-            const f3 P = { a0.x, a0.y, a0.z };
-            int px, py;
-            slotToPixel(fr, wp.slotBegin + nb.path / wp.R, px, py);
-            const uint32_t seed = (uint32_t)(fr.height * px + py);
-            const uint32_t hitOrdinal = wb.pathBase[nb.path] + (uint32_t)nb.depth;
-            uint32_t s = lcgSkip(seed, wp.mainStart + wp.drawsPerHit * hitOrdinal + drawPrefix + slot * perSample);
-            const rt_light& light = sc.lights[l];
-            f3 pos, col;
-            if (light.type == 0) {
-                pos = ld3(light.v + 0);
-                col = ld3(light.v + 3);
-            } else if (light.type == 1) {
-                sampleSegmentLight(next1d(s), light, pos, col);
-            } else {
-                const float sx = next1d(s);
-                const float sy = next1d(s);
-                sampleParallelogramLight({ sx, sy }, light, pos, col);
+        }
+        // One pass per distinct light among the wave's lanes (one, unless a wave straddles
+        // two lights), with the light's index uniform so that its data is read once per wave.
+        for (;;) {
+            const unsigned long long todo = __ballot(live);
+            if (todo == 0ull)
+                break;
+            const int lu = __builtin_amdgcn_readlane(l, __builtin_ctzll(todo));
+            if (live && l == lu) {
+                live = false;
+                // every lane in here has the same l; taking it from the first one keeps the index
+                // (and so the loads) scalar, which the lane's own, equal, l would not
+                const uint32_t lw = (uint32_t)__builtin_amdgcn_readfirstlane(l) * kLightWords;
+                rt_light light;
+                light.type = (int32_t)lights[lw];
+#pragma unroll
+                for (uint32_t k = 0; k < 21; k++)
+                    light.v[k] = __uint_as_float(lights[lw + 1u + k]);
+                const float4 a0 = wb.nodeA[4u * (size_t)node];
+                const f3 P = { a0.x, a0.y, a0.z };
+                int px, py;
+                slotToPixel(fr, wp.slotBegin + path / wp.R, px, py);
+                const uint32_t seed = (uint32_t)(fr.height * px + py);
+                const uint32_t hitOrdinal = wb.pathBase[path] + depth;
+                uint32_t s = lcgSkip(seed, wp.mainStart + wp.drawsPerHit * hitOrdinal + drawPrefix + slot * perSample);
+                f3 pos, col;
+                if (light.type == 0) {
+                    pos = ld3(light.v + 0);
+                    col = ld3(light.v + 3);
+                } else if (light.type == 1) {
+                    sampleSegmentLight(next1d(s), light, pos, col);
+                } else {
+                    const float sx = next1d(s);
+                    const float sy = next1d(s);
+                    sampleParallelogramLight({ sx, sy }, light, pos, col);
+                }
+                f3 d;
+                float len = 0.0f;
+                if (ft.shadows) { // src/light.cpp:94-97: from the light to the hit point
+                    const f3 toHit = P - pos;
+                    d = normalize(toHit);
+                    len = length(toHit);
+                } else { // src/light.cpp:270-272: no ray; keep minus the direction to the light
+                    d = -normalize(pos - P);
+                }
+                float4* sr = wb.srays + 3u * (size_t)item;
+                sr[0] = make_float4(pos.x, pos.y, pos.z, len);
+                sr[1] = make_float4(d.x, d.y, d.z, 0.0f);
+                sr[2] = make_float4(col.x, col.y, col.z, 0.0f);
+                wb.svis[item] = 1; // visible unless the traversal finds an occluder
             }
-            f3 d;
-            float len = 0.0f;
-            if (ft.shadows) { // src/light.cpp:94-97: from the light to the hit point
-                const f3 toHit = P - pos;
-                d = normalize(toHit);
-                len = length(toHit);
-            } else { // src/light.cpp:270-272: no ray; keep minus the direction to the light
-                d = -normalize(pos - P);
-            }
-            sr[0] = make_float4(pos.x, pos.y, pos.z, len);
-            sr[1] = make_float4(d.x, d.y, d.z, 0.0f);
-            sr[2] = make_float4(col.x, col.y, col.z, 0.0f);
-            wb.svis[item] = 1; // visible unless the traversal finds an occluder
         }
     }
 }
@@ -648,7 +677,7 @@ hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlock
         (void)hipEventRecord(marks[0], stream);
     const int pb = (int)((wp.nSlots + 255) / 256);
     hipLaunchKernelGGL(prefixKernel, dim3(pb), dim3(256), 0, stream, fr, wp, wb);
-    hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr);
+    hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr, sc.lights);
     if (marks)
         (void)hipEventRecord(marks[1], stream);
     hipLaunchKernelGGL(shadowVariant(stats), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
