@@ -163,8 +163,13 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
 // ---------------------------------------------------------------------------
 // 1b. the queued camera rays and their mirror chains
 // ---------------------------------------------------------------------------
+#ifdef RT_PATH_WAVES // experiments: force the register budget of this many waves per SIMD
+#define RT_PATH_ATTR __attribute__((amdgpu_waves_per_eu(RT_PATH_WAVES, RT_PATH_WAVES)))
+#else
+#define RT_PATH_ATTR
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(256) void pathKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+__global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
@@ -342,6 +347,21 @@ __global__ void prefixKernel(const DevFrame fr, const WfParams wp, const WfBuffe
     if (!slotToPixel(fr, wp.slotBegin + s, px, py))
         return;
     uint32_t base = 0;
+    if ((wp.R & 3u) == 0u) { // four paths at a time: one 4-B load of counts, one 16-B store of bases
+        const uint32_t* cnt = reinterpret_cast<const uint32_t*>(wb.pathCount) + (size_t)s * (wp.R / 4u);
+        uint4* dst = reinterpret_cast<uint4*>(wb.pathBase) + (size_t)s * (wp.R / 4u);
+        for (uint32_t i = 0; i < wp.R / 4u; i++) {
+            const uint32_t c = cnt[i];
+            uint4 b;
+            b.x = base;
+            b.y = b.x + (c & 0xffu);
+            b.z = b.y + ((c >> 8) & 0xffu);
+            b.w = b.z + ((c >> 16) & 0xffu);
+            base = b.w + (c >> 24);
+            dst[i] = b;
+        }
+        return;
+    }
     for (uint32_t i = 0; i < wp.R; i++) {
         const uint32_t path = s * wp.R + i;
         wb.pathBase[path] = base;
