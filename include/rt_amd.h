@@ -25,7 +25,7 @@ extern "C" {
 enum rt_status {
     RT_OK = 0,
     RT_ERR_INVALID = -1,     /* bad argument / malformed BVH */
-    RT_ERR_UNSUPPORTED = -2, /* feature outside this path (motion blur, bloom, SAH build) */
+    RT_ERR_UNSUPPORTED = -2, /* feature outside this path (motion blur, SAH build, bloom sizes the reference cannot run) */
     RT_ERR_DEVICE = -3,      /* HIP runtime failure */
     RT_ERR_STATE = -4        /* call order (render before scene upload, ...) */
 };
@@ -225,6 +225,33 @@ size_t rt_shard_floats(int width, int height, int shard_index, int shard_count);
  * Screen order.  Device pointers; enqueued on `stream`. */
 int rt_deinterleave(rt_ctx* ctx, const void* d_packed, int width, int height, int shard_count,
                     void* d_frame, void* stream);
+
+/* postprocessImageWithBloom (src/extra.cpp:276-316, called at the end of
+ * renderImage, src/render.cpp:48-50) on a whole frame in Screen order in device
+ * memory, in place, under the features last set; nothing happens when
+ * enableBloomEffect is off.  rt_render and rt_render_device with one shard run
+ * it themselves; a sharded frame needs it once, on the rank that holds the
+ * frame after rt_deinterleave (a shard has no neighbours).  Filter sizes the
+ * reference cannot run without writing outside its image (below 3) or
+ * overflowing its factorial (above 20) are refused by rt_features_set.  The
+ * reference's filter window reaches one row above the image (undefined
+ * behaviour there): those reads count as black here. */
+int rt_postprocess_device(rt_ctx* ctx, void* d_frame, int width, int height, void* stream);
+
+/* Screen::writeBitmapToFile (src/screen.cpp:44-55): clamp to [0,1], times 255,
+ * truncated to 8 bits, alpha 255 -- written as the pixel array of the file
+ * stbi_write_bmp produces for 4 components: rows bottom-up, bytes B G R A,
+ * width * height * 4 bytes at d_bgra (device memory).  rt_bmp_header writes the
+ * 122 bytes that precede them in the file (14-byte file header + 108-byte V4
+ * header, BI_BITFIELDS) into `out` and returns that size; with out == NULL it
+ * only returns the size. */
+int rt_pack_bmp_device(rt_ctx* ctx, const void* d_frame, int width, int height, void* d_bgra, void* stream);
+size_t rt_bmp_header(int width, int height, uint8_t* out, size_t out_bytes);
+
+/* Screen::writeBitmapToFile (src/screen.cpp:44-55) for a frame in host memory
+ * (width * height * 3 floats, Screen order): the same conversion on the device,
+ * then the file.  Not a hot path: allocates and frees its device buffers. */
+int rt_write_bmp(rt_ctx* ctx, const float* rgb, int width, int height, const char* path);
 
 /* Blocks until the work rt_render_device / rt_deinterleave enqueued on
  * `stream` has finished; stats (optional) receives the ray count of the last

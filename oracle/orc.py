@@ -204,3 +204,22 @@ def linear_gradient_sample(ti: float):
     out = np.zeros(3, dtype=np.float32)
     lib().orc_linear_gradient_sample_r(C.c_float(ti), _p(out))
     return out
+
+
+def bloom(features, image: np.ndarray) -> np.ndarray:
+    """postprocessImageWithBloom on an (H, W, 3) float32 frame in Screen order; returns a new frame."""
+    f = np.ascontiguousarray(features, dtype=sio.FEATURES)
+    out = np.ascontiguousarray(image, dtype=np.float32).copy()
+    h, w = out.shape[:2]
+    if lib().orc_bloom(_p(f), _p(out), int(w), int(h)) != 0:
+        raise RuntimeError("oracle: bloom filter size the reference cannot run (outside [3, 20])")
+    return out
+
+
+def bmp_bytes(image: np.ndarray) -> bytes:
+    """The bytes of the file Screen::writeBitmapToFile writes for an (H, W, 3) float32 frame."""
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    h, w = img.shape[:2]
+    out = np.zeros(122 + w * h * 4, dtype=np.uint8)
+    lib().orc_bmp_bytes(_p(img), int(w), int(h), _p(out))
+    return out.tobytes()

@@ -1042,10 +1042,122 @@ void orc_intersect_batch(const orc_scene* scene, const orc_features* features, o
         *stats = total;
 }
 
+// postprocessImageWithBloom and its helpers, src/extra.cpp:214-316, on a frame in Screen order
+// (pixel (x, y) at flat index (H - 1 - y) * W + x, src/screen.cpp:36-42, :128-131), statement by
+// statement and in place like the reference.  Two things there are undefined behaviour and have
+// to be given a meaning: filter sizes below 3 write outside the image and above 20 overflow
+// factorial() (refused, -1), and the filter window reaches one row above the image (flat index
+// below zero): such a read counts as black.  A flat index inside the buffer is read whatever
+// column arithmetic produced it, as there.
+int orc_bloom(const orc_features* features, float* rgb, int width, int height)
+{
+    if (!features->enableBloomEffect)
+        return 0;
+    const int k = int(features->bloomFilterSize);
+    if (k < 3 || k > 20)
+        return -1;
+    const long long n = (long long)width * height;
+    std::vector<V3> image(n), thresholded(n);
+    for (long long i = 0; i < n; i++)
+        image[i] = thresholded[i] = V3 { rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] };
+    auto indexAt = [&](int x, int y) { return (long long)(height - 1 - y) * width + x; };
+
+    // computeHighpassFilter, :214-226
+    const V3 luminanceVector { 0.2126f, 0.7152f, 0.0722f };
+    for (V3& pixel : thresholded) {
+        const float luminance = dot(luminanceVector, pixel);
+        if (luminance < features->bloomThreshold)
+            pixel = V3 { 0.f, 0.f, 0.f };
+    }
+
+    // computeGaussianFilter, :239-271 (both passes, the second overwrites the first)
+    auto factorial = [](int m) {
+        long long f = 1;
+        for (int i = 1; i <= m; i++)
+            f *= i;
+        return f;
+    };
+    std::vector<std::vector<float>> filter(k, std::vector<float>(k));
+    for (int y = 0; y < k; y++) {
+        float total = 0;
+        for (int x = 0; x < k; x++) {
+            const float val = float(factorial(k) / (factorial(x) * factorial(k - x)));
+            total += val;
+            filter[x][y] = val;
+        }
+        for (int x = 0; x < k; x++)
+            filter[x][y] /= total;
+    }
+    for (int x = 0; x < k; x++) {
+        float total = 0;
+        for (int y = 0; y < k; y++) {
+            const float val = float(factorial(k) / (factorial(y) * factorial(k - y)));
+            total += val;
+            filter[x][y] = val;
+        }
+        for (int y = 0; y < k; y++)
+            filter[x][y] /= total;
+    }
+
+    // :296-308
+    for (int x = k - 2; x < width - k + 2; x++) {
+        for (int y = k - 2; y < height - k + 2; y++) {
+            V3 color { 0.f, 0.f, 0.f };
+            for (int i = 0; i < k; i++) {
+                for (int j = 0; j < k; j++) {
+                    const long long idx = indexAt(x + i, y + j);
+                    const V3 px = (idx >= 0 && idx < n) ? thresholded[idx] : V3 { 0.f, 0.f, 0.f };
+                    color = color + filter[i][j] * px;
+                }
+            }
+            thresholded[indexAt(x, y)] = color;
+        }
+    }
+    // :311-315
+    for (int x = 0; x < width; x++)
+        for (int y = 0; y < height; y++)
+            image[indexAt(x, y)] = image[indexAt(x, y)] + thresholded[indexAt(x, y)];
+    for (long long i = 0; i < n; i++)
+        rgb[3 * i] = image[i].x, rgb[3 * i + 1] = image[i].y, rgb[3 * i + 2] = image[i].z;
+    return 0;
+}
+
+// Screen::writeBitmapToFile, src/screen.cpp:44-55, through stbi_write_bmp with 4 components
+// (framework/third_party/stb/include/stb/stb_image_write.h:492-510): 14-byte file header, 108-byte
+// V4 header (BI_BITFIELDS, 32 bpp), then the rows bottom-up, each pixel as B, G, R, A.
+// `out` receives 122 + width * height * 4 bytes.
+void orc_bmp_bytes(const float* rgb, int width, int height, uint8_t* out)
+{
+    auto put16 = [&](size_t at, uint32_t v) { out[at] = uint8_t(v & 255), out[at + 1] = uint8_t((v >> 8) & 255); };
+    auto put32 = [&](size_t at, uint32_t v) { put16(at, v & 0xffff), put16(at + 2, v >> 16); };
+    std::memset(out, 0, 122);
+    out[0] = 'B', out[1] = 'M';
+    put32(2, uint32_t(14 + 108 + (size_t)width * height * 4));
+    put32(10, 14 + 108);
+    put32(14, 108), put32(18, uint32_t(width)), put32(22, uint32_t(height));
+    put16(26, 1), put16(28, 32);
+    put32(30, 3);
+    put32(54, 0xff0000u), put32(58, 0xff00u), put32(62, 0xffu), put32(66, 0xff000000u);
+    uint8_t* px = out + 122;
+    for (int row = height - 1; row >= 0; row--) { // stb: vdir -1, the last row of the data first
+        for (int x = 0; x < width; x++) {
+            const float* c = rgb + 3 * ((size_t)row * width + x);
+            uint8_t v[3];
+            for (int ch = 0; ch < 3; ch++) {
+                const float clamped = std::min(std::max(c[ch], 0.0f), 1.0f); // glm::clamp
+                v[ch] = uint8_t(clamped * 255.0f);                             // glm::u8vec4(vec4): truncation
+            }
+            *px++ = v[2], *px++ = v[1], *px++ = v[0], *px++ = 255;
+        }
+    }
+}
+
 int orc_render(const orc_scene* scene, const orc_features* features, const orc_camera* camera, int width, int height,
     float* out_rgb, orc_stats* stats, int policy, int threads)
 {
-    if (features->enableMotionBlur || features->enableBloomEffect)
+    if (features->enableMotionBlur)
+        return -1;
+    if (features->enableBloomEffect && (features->bloomFilterSize < 3 || features->bloomFilterSize > 20))
         return -1;
     const Camera cam(*camera);
     orc_stats total {};
@@ -1077,7 +1189,7 @@ int orc_render(const orc_scene* scene, const orc_features* features, const orc_c
     }
     if (stats)
         *stats = total;
-    return 0;
+    return orc_bloom(features, out_rgb, width, height); // src/render.cpp:48-50
 }
 
 void orc_primary_hits(const orc_scene* scene, const orc_features* features, const orc_camera* camera, int width,

@@ -183,7 +183,17 @@ void orc_intersect_batch(const orc_scene* scene, const orc_features* features,
 /* renderImage (src/render.cpp:19-51).  out_rgb: width*height*3 floats in
  * Screen order, index (height-1-y)*width+x (src/screen.cpp:36-42).
  * threads <= 0: all OpenMP threads.  Returns 0, -1 for unsupported features
- * (motion blur, bloom). */
+ * (motion blur; bloom filter sizes outside [3, 20], which the reference itself
+ * cannot run without undefined behaviour). */
+/* postprocessImageWithBloom (src/extra.cpp:276-316) on a frame in Screen order,
+ * in place; no-op when enableBloomEffect is off.  Returns 0, or -1 for a filter
+ * size outside [3, 20]. */
+int orc_bloom(const orc_features* features, float* rgb, int width, int height);
+
+/* The bytes of the file Screen::writeBitmapToFile writes (src/screen.cpp:44-55):
+ * 122 header bytes + width * height * 4 pixel bytes into `out`. */
+void orc_bmp_bytes(const float* rgb, int width, int height, uint8_t* out);
+
 int orc_render(const orc_scene* scene, const orc_features* features,
                const orc_camera* camera, int width, int height, float* out_rgb,
                orc_stats* stats, int policy, int threads);

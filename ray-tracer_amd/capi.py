@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")  
 EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_bvh_build", "rt_scene_upload", "rt_lights_set",
     "rt_features_set", "rt_render", "rt_render_device", "rt_shard_floats", "rt_deinterleave", "rt_sync",
-    "rt_intersect_batch", "rt_eval_batch",
+    "rt_intersect_batch", "rt_eval_batch", "rt_postprocess_device", "rt_pack_bmp_device", "rt_bmp_header", "rt_write_bmp",
 ]
 
 (EVAL_BARYCENTRIC, EVAL_INTERP_NORMAL, EVAL_INTERP_TEXCOORD, EVAL_TEX_NEAREST, EVAL_TEX_BILINEAR,
@@ -65,6 +65,7 @@ def lib():
         l.rt_last_error.restype = C.c_char_p
         l.rt_last_error.argtypes = [C.c_void_p]
         l.rt_shard_floats.restype = C.c_size_t
+        l.rt_bmp_header.restype = C.c_size_t
         l.rt_ctx_destroy.argtypes = [C.c_void_p]
         l.rt_ctx_destroy.restype = None
         _lib = l
@@ -87,6 +88,14 @@ def bvh_build(prims: np.ndarray, sah_binning: bool = False):
     if rc != 0:
         raise RtError(rc, lib().rt_last_error(None).decode())
     return nodes[:nn.value].copy(), out, nl.value, nf.value
+
+
+def bmp_header(width, height) -> bytes:
+    """The 122 bytes stbi_write_bmp puts before the pixel array of a 4-component image."""
+    n = int(lib().rt_bmp_header(int(width), int(height), None, C.c_size_t(0)))
+    buf = (C.c_uint8 * n)()
+    lib().rt_bmp_header(int(width), int(height), buf, C.c_size_t(n))
+    return bytes(buf)
 
 
 def shard_floats(width, height, shard, n_shard) -> int:
@@ -171,6 +180,20 @@ class Context:
     def deinterleave(self, d_packed_ptr: int, width, height, n_shard, d_frame_ptr: int, stream: int = 0):
         self._check(lib().rt_deinterleave(self.handle, C.c_void_p(d_packed_ptr), int(width), int(height), int(n_shard),
                                           C.c_void_p(d_frame_ptr), C.c_void_p(stream)))
+
+    def postprocess(self, d_frame_ptr: int, width, height, stream: int = 0):
+        """postprocessImageWithBloom on a device frame, in place (no-op unless enableBloomEffect)."""
+        self._check(lib().rt_postprocess_device(self.handle, C.c_void_p(d_frame_ptr), int(width), int(height), C.c_void_p(stream)))
+
+    def pack_bmp(self, d_frame_ptr: int, width, height, d_bgra_ptr: int, stream: int = 0):
+        """Screen::writeBitmapToFile's 8-bit conversion into the bitmap file's pixel array (device memory)."""
+        self._check(lib().rt_pack_bmp_device(self.handle, C.c_void_p(d_frame_ptr), int(width), int(height),
+                                              C.c_void_p(d_bgra_ptr), C.c_void_p(stream)))
+
+    def write_bmp(self, image: np.ndarray, path: str):
+        """Screen::writeBitmapToFile for an (H, W, 3) float32 frame in host memory."""
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        self._check(lib().rt_write_bmp(self.handle, _p(img), int(img.shape[1]), int(img.shape[0]), str(path).encode()))
 
     def sync(self, stream: int = 0):
         st = Stats()

@@ -19,6 +19,7 @@
 
 #include "rt_device.hpp"
 #include "rt_wavefront.hpp"
+#include "rt_post.hpp"
 
 namespace rt {
 hipError_t renderOccupancy(int variant, int blockThreads, size_t ldsBytes, int* blocksPerCU);
@@ -42,6 +43,8 @@ struct rt_ctx {
     int numCU = 256;
     std::string error;
     // device buffers
+    float* dBloom = nullptr; // thresholded copy of the frame for the bloom pass
+    size_t bloomCap = 0;     // floats
     uint4* dPairs = nullptr;
     uint32_t numPairs = 0; // pair records in dPairs
     float4* dTris = nullptr;
@@ -181,7 +184,7 @@ void rt_ctx_destroy(rt_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = { ctx->dPairs, ctx->dTris, ctx->dAttrs, ctx->dMats, ctx->dTexs, ctx->dTexels, ctx->dSpheres, ctx->dLights,
-        ctx->dCounters, ctx->dFrame };
+        ctx->dCounters, ctx->dFrame, ctx->dBloom };
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -731,8 +734,10 @@ int rt_features_set(rt_ctx* ctx, const rt_features* f)
         return fail(ctx, RT_ERR_INVALID, "rt_features_set: NULL argument");
     if (f->enableMotionBlur)
         return fail(ctx, RT_ERR_UNSUPPORTED, "rt_features_set: motion blur (renderImageWithMotionBlur) is outside this path");
-    if (f->enableBloomEffect)
-        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_features_set: bloom post-processing is outside this path");
+    if (f->enableBloomEffect && (f->bloomFilterSize < (uint32_t)kBloomMinSize || f->bloomFilterSize > (uint32_t)kBloomMaxSize))
+        return fail(ctx, RT_ERR_UNSUPPORTED,
+            "rt_features_set: bloomFilterSize %u: below %d the reference's filter loop writes outside the image, above %d its factorial overflows",
+            f->bloomFilterSize, kBloomMinSize, kBloomMaxSize);
     if (f->shadingModel < 0 || f->shadingModel > 3)
         return fail(ctx, RT_ERR_INVALID, "rt_features_set: shadingModel %d", f->shadingModel);
     if (f->maxRayDepth < 0 || f->maxRayDepth > kMaxDepth)
@@ -814,6 +819,28 @@ static size_t shardTiles(int width, int height, int shard, int nShard)
 {
     const size_t tiles = static_cast<size_t>((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
     return (tiles > static_cast<size_t>(shard)) ? (tiles - shard + nShard - 1) / nShard : 0;
+}
+
+// postprocessImageWithBloom (src/extra.cpp:276-316) on a whole frame in Screen order, in place.
+static int bloomDevice(rt_ctx* ctx, float* dFrame, int width, int height, hipStream_t stream)
+{
+    const rt_features& F = ctx->features;
+    if (!F.enableBloomEffect)
+        return RT_OK;
+    const size_t floats = static_cast<size_t>(width) * height * 3;
+    if (floats > ctx->bloomCap) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        if (ctx->dBloom)
+            (void)hipFree(ctx->dBloom);
+        ctx->dBloom = nullptr;
+        ctx->bloomCap = 0;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->dBloom), floats * sizeof(float)));
+        ctx->bloomCap = floats;
+    }
+    BloomWeights w;
+    bloomWeights(static_cast<int>(F.bloomFilterSize), w);
+    HIP_TRY(ctx, launchBloom(stream, dFrame, ctx->dBloom, width, height, static_cast<int>(F.bloomFilterSize), F.bloomThreshold, w));
+    return RT_OK;
 }
 
 static int traceKnobs(int minActive, int a, int b)
@@ -988,6 +1015,11 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                               traceKnobs(ctx->minActiveShadow, ctx->parkAShadow, ctx->parkBShadow), marks, ctx->numCU));
         }
     }
+    if (nShard == 1) { // a shard has no neighbours: a sharded frame is post-processed after its gather (rt_postprocess_device)
+        const int rb = bloomDevice(ctx, dOut, width, height, stream);
+        if (rb != RT_OK)
+            return rb;
+    }
     if (timeIt) {
         HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed + 4], stream));
         ctx->evUsed += 5;
@@ -1106,6 +1138,92 @@ int rt_render_device(rt_ctx* ctx, const rt_camera* camera, int width, int height
             stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return RT_OK;
+}
+
+int rt_postprocess_device(rt_ctx* ctx, void* d_frame, int width, int height, void* stream)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_postprocess_device: ctx is NULL");
+    if (!ctx->haveFeatures)
+        return fail(ctx, RT_ERR_STATE, "rt_postprocess_device: no features set (rt_features_set)");
+    if (!d_frame || width <= 0 || height <= 0)
+        return fail(ctx, RT_ERR_INVALID, "rt_postprocess_device: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bloomDevice(ctx, static_cast<float*>(d_frame), width, height, static_cast<hipStream_t>(stream));
+}
+
+int rt_pack_bmp_device(rt_ctx* ctx, const void* d_frame, int width, int height, void* d_bgra, void* stream)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_pack_bmp_device: ctx is NULL");
+    if (!d_frame || !d_bgra || width <= 0 || height <= 0)
+        return fail(ctx, RT_ERR_INVALID, "rt_pack_bmp_device: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launchPackBmp(static_cast<hipStream_t>(stream), static_cast<const float*>(d_frame), static_cast<uint8_t*>(d_bgra), width, height));
+    return RT_OK;
+}
+
+int rt_write_bmp(rt_ctx* ctx, const float* rgb, int width, int height, const char* path)
+{
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_write_bmp: ctx is NULL");
+    if (!rgb || !path || width <= 0 || height <= 0)
+        return fail(ctx, RT_ERR_INVALID, "rt_write_bmp: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t pixels = static_cast<size_t>(width) * height;
+    float* dRgb = nullptr;
+    uint8_t* dOut = nullptr;
+    std::vector<uint8_t> file(122 + pixels * 4);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dRgb), pixels * 12);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&dOut), pixels * 4);
+    if (e == hipSuccess)
+        e = hipMemcpy(dRgb, rgb, pixels * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = launchPackBmp(nullptr, dRgb, dOut, width, height);
+    if (e == hipSuccess)
+        e = hipMemcpy(file.data() + 122, dOut, pixels * 4, hipMemcpyDeviceToHost);
+    if (dRgb)
+        (void)hipFree(dRgb);
+    if (dOut)
+        (void)hipFree(dOut);
+    if (e != hipSuccess)
+        return fail(ctx, RT_ERR_DEVICE, "rt_write_bmp: %s", hipGetErrorString(e));
+    rt_bmp_header(width, height, file.data(), 122);
+    FILE* fh = std::fopen(path, "wb");
+    if (!fh)
+        return fail(ctx, RT_ERR_INVALID, "rt_write_bmp: cannot open %s", path);
+    const size_t wrote = std::fwrite(file.data(), 1, file.size(), fh);
+    std::fclose(fh);
+    if (wrote != file.size())
+        return fail(ctx, RT_ERR_INVALID, "rt_write_bmp: short write to %s", path);
+    return RT_OK;
+}
+
+size_t rt_bmp_header(int width, int height, uint8_t* out, size_t out_bytes)
+{
+    // stbi_write_bmp for 4 components: 14-byte file header + 108-byte V4 header,
+    // BI_BITFIELDS, 32 bpp, masks R 0xff0000 G 0xff00 B 0xff A 0xff000000
+    const size_t kBytes = 14 + 108;
+    if (!out || out_bytes < kBytes || width <= 0 || height <= 0)
+        return kBytes;
+    std::memset(out, 0, kBytes);
+    auto put16 = [&](size_t at, uint32_t v) { out[at] = v & 255, out[at + 1] = (v >> 8) & 255; };
+    auto put32 = [&](size_t at, uint32_t v) { put16(at, v & 0xffff), put16(at + 2, v >> 16); };
+    out[0] = 'B', out[1] = 'M';
+    put32(2, static_cast<uint32_t>(kBytes + static_cast<size_t>(width) * height * 4));
+    put32(10, static_cast<uint32_t>(kBytes));
+    put32(14, 108);
+    put32(18, static_cast<uint32_t>(width));
+    put32(22, static_cast<uint32_t>(height));
+    put16(26, 1);
+    put16(28, 32);
+    put32(30, 3);
+    put32(54, 0xff0000u);
+    put32(58, 0xff00u);
+    put32(62, 0xffu);
+    put32(66, 0xff000000u);
+    return kBytes;
 }
 
 int rt_sync(rt_ctx* ctx, void* stream, rt_stats* stats)

@@ -136,6 +136,33 @@ static void renderAgainstOracle()
     CHECK(sum > 100.0);
     CHECK(maxAbs <= 2e-5);
 
+    // bloom inside renderImage (src/render.cpp:48-50) and Screen::writeBitmapToFile, against the oracle
+    Features bloom = f;
+    bloom.extra.enableBloomEffect = true;
+    bloom.extra.bloomFilterSize = 4;
+    bloom.extra.bloomThreshold = 0.3f;
+    Screen bright(ivec2(W, H));
+    renderImage(scene, bvh, bloom, camera, bright);
+    rt_features bf = detail::toC(bloom);
+    orc_features obf;
+    std::memcpy(&obf, &bf, sizeof obf);
+    std::vector<float> expect(got, got + ref.size()); // the un-bloomed device frame through the oracle's bloom
+    CHECK(orc_bloom(&obf, expect.data(), W, H) == 0);
+    CHECK(std::memcmp(expect.data(), bright.pixels().data(), expect.size() * sizeof(float)) == 0);
+    CHECK(std::memcmp(expect.data(), got, expect.size() * sizeof(float)) != 0);
+    const std::filesystem::path bmp = std::filesystem::temp_directory_path() / "rt_amd_host_test.bmp";
+    bright.writeBitmapToFile(bmp);
+    std::vector<uint8_t> want(122 + size_t(W) * H * 4), have(want.size() + 1);
+    orc_bmp_bytes(reinterpret_cast<const float*>(bright.pixels().data()), W, H, want.data());
+    FILE* fh = std::fopen(bmp.string().c_str(), "rb");
+    CHECK(fh != nullptr);
+    if (fh) {
+        const size_t n = std::fread(have.data(), 1, have.size(), fh);
+        std::fclose(fh);
+        CHECK(n == want.size() && std::memcmp(have.data(), want.data(), n) == 0);
+        std::filesystem::remove(bmp);
+    }
+
     // error behaviour: unsupported features throw, like the reference's loaders do
     Features blur = f;
     blur.extra.enableMotionBlur = true;

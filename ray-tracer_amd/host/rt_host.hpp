@@ -21,6 +21,7 @@
 #include <stdexcept>
 #include <string>
 #include <variant>
+#include <filesystem>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -434,6 +435,12 @@ public:
     int indexAt(int x, int y) const { return (m_resolution.y - 1 - y) * m_resolution.x + x; } // src/screen.cpp:119-122
     const std::vector<vec3>& pixels() const { return m_textureData; }
     std::vector<vec3>& pixels() { return m_textureData; }
+    // src/screen.cpp:44-55; the 8-bit conversion runs on the device
+    void writeBitmapToFile(const std::filesystem::path& filePath)
+    {
+        Device& dev = Device::get();
+        dev.check(rt_write_bmp(dev.ctx(), &m_textureData[0].x, m_resolution.x, m_resolution.y, filePath.string().c_str()), "rt_write_bmp");
+    }
 
 private:
     ivec2 m_resolution;

@@ -235,7 +235,7 @@ def test_error_behaviour(ctx):
     with pytest.raises(capi.RtError) as e:
         fresh.render(sio.default_camera(8, 8), 8, 8)
     assert e.value.code == -4  # no features
-    for bad in (dict(enableMotionBlur=1), dict(enableBloomEffect=1)):
+    for bad in (dict(enableMotionBlur=1), dict(enableBloomEffect=1, bloomFilterSize=2), dict(enableBloomEffect=1, bloomFilterSize=21)):
         with pytest.raises(capi.RtError) as e:
             fresh.set_features(common.features(**bad))
         assert e.value.code == -2
@@ -254,6 +254,60 @@ def test_error_behaviour(ctx):
     with pytest.raises(capi.RtError):
         fresh.upload_scene(scn, loop, prims)
     fresh.close()
+
+
+@pytest.mark.parametrize("k,threshold", [(3, 0.5), (5, 0.2), (8, 0.0)])
+def test_bloom_matches_oracle(ctx, k, threshold):
+    """postprocessImageWithBloom: inside renderImage (rt_render) and on its own (rt_postprocess_device), bit for bit."""
+    import torch
+    scn = common.scene("CornellBox")
+    osc = _both(ctx, scn)
+    f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2,
+                        enableBloomEffect=1, bloomFilterSize=k, bloomThreshold=threshold)
+    w, h = 67, 45
+    cam = sio.default_camera(w, h)
+    want, so = osc.render(f, cam, w, h, policy=1)
+    ctx.set_features(f)
+    got, st = ctx.render(cam, w, h)
+    plain_f = f.copy()
+    plain_f["enableBloomEffect"] = 0
+    ctx.set_features(plain_f)
+    plain, _ = ctx.render(cam, w, h)
+    assert st["rays"] == so["rays"]
+    assert not np.array_equal(got, plain)  # the effect did something
+    # the device's own frame through the oracle's bloom: the post-process alone has to agree to the bit
+    assert np.array_equal(orc.bloom(f, plain).view(np.uint32), got.view(np.uint32))
+    assert common.image_error(got, want)[0] <= 2e-5
+    # on its own entry point, on a frame with values on both sides of the threshold and above one
+    rng = np.random.default_rng(k)
+    frame = (rng.random((h, w, 3), dtype=np.float32) * np.float32(1.6)).astype(np.float32)
+    ctx.set_features(f)
+    d = torch.from_numpy(frame.copy()).cuda()
+    ctx.postprocess(d.data_ptr(), w, h)
+    ctx.sync(0)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), orc.bloom(f, frame).view(np.uint32))
+    ctx.set_features(plain_f)
+    d2 = torch.from_numpy(frame.copy()).cuda()
+    ctx.postprocess(d2.data_ptr(), w, h)  # disabled: the frame stays as it is
+    ctx.sync(0)
+    assert np.array_equal(d2.cpu().numpy(), frame)
+
+
+def test_bmp_packing_matches_oracle(ctx):
+    """Screen::writeBitmapToFile: header and pixel bytes of the file."""
+    import torch
+    w, h = 53, 31
+    rng = np.random.default_rng(7)
+    frame = (rng.random((h, w, 3), dtype=np.float32) * np.float32(1.5) - np.float32(0.25)).astype(np.float32)
+    frame[0, 0] = (1.0, 0.0, 0.999999)
+    want = orc.bmp_bytes(frame)
+    d = torch.from_numpy(frame).cuda()
+    out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    ctx.pack_bmp(d.data_ptr(), w, h, out.data_ptr())
+    ctx.sync(0)
+    got = capi.bmp_header(w, h) + out.cpu().numpy().tobytes()
+    assert len(got) == 122 + w * h * 4
+    assert got == want
 
 
 def test_empty_scene_and_spheres(ctx):

@@ -242,3 +242,84 @@ def test_culling_policy_changes_no_pixel():
     b, sb = osc.render(f, cam, 160, 90, policy=1)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert sa["rays"] == sb["rays"] and sb["inner_nodes"] <= sa["inner_nodes"]
+
+
+# ---------------------------------------------------------------------------
+# post-processing (src/extra.cpp:214-316, src/screen.cpp:44-55): no test or output of the
+# reference covers these, so the restatement is checked against an independent numpy form of
+# the same statements (parity with the reference itself: unpinned)
+# ---------------------------------------------------------------------------
+def _numpy_bloom(frame, k, threshold):
+    from math import factorial
+    h, w = frame.shape[:2]
+    flat = frame.reshape(-1, 3).astype(np.float32)
+    lum = (np.float32(0.2126) * flat[:, 0] + np.float32(0.7152) * flat[:, 1]) + np.float32(0.0722) * flat[:, 2]
+    t = flat.copy()
+    t[lum < np.float32(threshold)] = 0
+    vals = [np.float32(factorial(k) // (factorial(y) * factorial(k - y))) for y in range(k)]
+    total = np.float32(0)
+    for v in vals:
+        total = np.float32(total + v)
+    wgt = [np.float32(v / total) for v in vals]
+    out = t.copy()
+    xs = np.arange(k - 2, w - k + 2)
+    ys = np.arange(k - 2, h - k + 2)
+    if len(xs) and len(ys):
+        X, Y = np.meshgrid(xs, ys, indexing="ij")
+        acc = np.zeros(X.shape + (3,), dtype=np.float32)
+        for i in range(k):
+            for j in range(k):
+                idx = (h - 1 - (Y + j)).astype(np.int64) * w + (X + i)
+                ok = (idx >= 0) & (idx < w * h)
+                px = np.where(ok[..., None], t[np.clip(idx, 0, w * h - 1)], np.float32(0))
+                acc = (acc + wgt[j] * px).astype(np.float32)
+        out[(h - 1 - Y) * w + X] = acc
+    return (flat + out).astype(np.float32).reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("k,threshold,w,h", [(3, 0.5, 23, 17), (4, 0.3, 16, 9), (7, 0.0, 31, 20), (20, 0.4, 45, 41), (5, 0.5, 6, 5)])
+def test_bloom_restatement_against_numpy_form(k, threshold, w, h):
+    rng = np.random.default_rng(100 + k)
+    frame = (rng.random((h, w, 3), dtype=np.float32) * np.float32(1.4)).astype(np.float32)
+    f = sio.default_features(enableBloomEffect=1, bloomFilterSize=k, bloomThreshold=threshold)
+    got = orc.bloom(f, frame)
+    want = _numpy_bloom(frame, k, threshold)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    off = sio.default_features(enableBloomEffect=0)
+    assert np.array_equal(orc.bloom(off, frame), frame)
+    for bad in (1, 2, 21):
+        with pytest.raises(RuntimeError):
+            orc.bloom(sio.default_features(enableBloomEffect=1, bloomFilterSize=bad), frame)
+
+
+def test_bloom_filter_columns_sum_to_one_and_weights_are_binomial():
+    # computeGaussianFilter: filter[x][y] = C(k, y) / sum_{y<k} C(k, y); for k = 3: 1/7, 3/7, 3/7.
+    # A frame that is white everywhere, threshold 0: an inner pixel becomes 1 + k * (column sum) = 1 + k.
+    k, w, h = 3, 12, 12
+    frame = np.ones((h, w, 3), dtype=np.float32)
+    out = orc.bloom(sio.default_features(enableBloomEffect=1, bloomFilterSize=k, bloomThreshold=0.0), frame)
+    assert abs(float(out[h // 2, w // 2, 0]) - (1.0 + k)) < 1e-5
+    assert float(out[0, 0, 0]) == 2.0  # outside the filtered range: the frame plus its thresholded self
+    one = np.zeros((h, w, 3), dtype=np.float32)
+    one[h - 1 - 6, 6] = 1.0  # pixel (6, 6)
+    o = orc.bloom(sio.default_features(enableBloomEffect=1, bloomFilterSize=k, bloomThreshold=0.5), one)
+    col = [float(o[h - 1 - (6 - j), 6, 0]) for j in range(k)]  # pixels (6, 6 - j) see it through filter[0][j]
+    assert np.allclose(col, [1.0 + 1.0 / 7.0, 3.0 / 7.0, 3.0 / 7.0], atol=1e-6)
+
+
+def test_bmp_bytes_layout():
+    import struct
+    w, h = 5, 3
+    frame = np.zeros((h, w, 3), dtype=np.float32)
+    frame[0, 1] = (1.0, 0.5, 0.25)   # top row, second pixel
+    frame[2, 4] = (2.0, -1.0, 0.999)  # bottom row, clamped
+    b = orc.bmp_bytes(frame)
+    assert b[:2] == b"BM" and len(b) == 122 + w * h * 4
+    size, _, off = struct.unpack_from("<IIi", b, 2)
+    assert size == len(b) and off == 122
+    hdr, bw, bh, planes, bpp, comp = struct.unpack_from("<IiiHHI", b, 14)
+    assert (hdr, bw, bh, planes, bpp, comp) == (108, w, h, 1, 32, 3)
+    assert struct.unpack_from("<IIII", b, 54) == (0xff0000, 0xff00, 0xff, 0xff000000)
+    px = np.frombuffer(b, dtype=np.uint8, offset=122).reshape(h, w, 4)  # file rows: bottom-up
+    assert tuple(px[h - 1, 1]) == (63, 127, 255, 255)  # B G R A of the top row's pixel, truncated
+    assert tuple(px[0, 4]) == (254, 0, 255, 255)
