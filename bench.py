@@ -168,6 +168,7 @@ def main():
             sharding.gather_packed(packed, rank, world, dist, gathered)
             if rank == 0:
                 ctx.deinterleave(gathered.data_ptr(), width, height, world, frame.data_ptr(), sptr)
+                ctx.postprocess(frame.data_ptr(), width, height, sptr)  # bloom needs the whole frame (no-op when off)
 
     def fence():
         if world > 1:
