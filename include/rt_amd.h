@@ -25,7 +25,7 @@ extern "C" {
 enum rt_status {
     RT_OK = 0,
     RT_ERR_INVALID = -1,     /* bad argument / malformed BVH */
-    RT_ERR_UNSUPPORTED = -2, /* feature outside this path (motion blur, SAH build, bloom sizes the reference cannot run) */
+    RT_ERR_UNSUPPORTED = -2, /* feature outside this path (motion blur, bloom sizes the reference cannot run) */
     RT_ERR_DEVICE = -3,      /* HIP runtime failure */
     RT_ERR_STATE = -4        /* call order (render before scene upload, ...) */
 };
@@ -176,9 +176,10 @@ void rt_ctx_destroy(rt_ctx* ctx);
 const char* rt_last_error(const rt_ctx* ctx);
 
 /* BVH::BVH(scene, features), src/bvh.cpp:52-101 with buildRecursive
- * (:424-493) and the median split (:208-223); host code.  prims_in is the
- * scene-order primitive list (:66-77).  nodes_out needs max(2, 2*n) entries,
- * prims_out n entries.  sah_binning != 0 -> RT_ERR_UNSUPPORTED. */
+ * (:424-493) and the median split (:208-223) or, with sah_binning != 0
+ * (Features::extra.enableBvhSahBinning), splitPrimitivesBySAHBin
+ * (src/extra.cpp:493-543); host code.  prims_in is the scene-order primitive
+ * list (:66-77).  nodes_out needs max(2, 2*n) entries, prims_out n entries. */
 int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_node* nodes_out,
                  rt_primitive* prims_out, uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves);
 

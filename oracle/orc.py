@@ -56,14 +56,14 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def bvh_build(prims: np.ndarray):
+def bvh_build(prims: np.ndarray, sah_binning: bool = False):
     """BVH::BVH: returns (nodes, primitives, num_levels, num_leaves)."""
     prims = np.ascontiguousarray(prims, dtype=sio.PRIMITIVE)
     n = len(prims)
     nodes = np.zeros(max(2, 2 * n), dtype=sio.NODE)
     out = np.zeros(n, dtype=sio.PRIMITIVE)
     nn, nl, nf = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    rc = lib().orc_bvh_build(_p(prims), C.c_uint32(n), 0, _p(nodes), _p(out), C.byref(nn), C.byref(nl), C.byref(nf))
+    rc = lib().orc_bvh_build(_p(prims), C.c_uint32(n), int(sah_binning), _p(nodes), _p(out), C.byref(nn), C.byref(nl), C.byref(nf))
     assert rc == 0
     return nodes[:nn.value].copy(), out, nl.value, nf.value
 

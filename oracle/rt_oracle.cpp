@@ -358,9 +358,65 @@ size_t splitPrimitivesByMedian(uint32_t axis, orc_primitive* prims, size_t n)
     return (n + 1) / 2;
 }
 
+// src/extra.cpp:475-483
+float computeSurfaceArea(const AABB& aabb)
+{
+    const float x = aabb.upper.x - aabb.lower.x;
+    const float y = aabb.upper.y - aabb.lower.y;
+    const float z = aabb.upper.z - aabb.lower.z;
+    return 2 * (x * y + x * z + y * z);
+}
+AABB mergeAABBs(const AABB& a, const AABB& b)
+{
+    return { { std::min(a.lower.x, b.lower.x), std::min(a.lower.y, b.lower.y), std::min(a.lower.z, b.lower.z) },
+        { std::max(a.upper.x, b.upper.x), std::max(a.upper.y, b.upper.y), std::max(a.upper.z, b.upper.z) } };
+}
+// splitPrimitivesBySAHBin, src/extra.cpp:493-543, statement by statement: eleven buckets of
+// ten bins' width along the axis, primitives re-ordered bucket by bucket (order inside a
+// bucket kept), then the cost of EVERY split position, where the box on the right lags one
+// primitive behind its count, and the first cheapest position wins.  A node without extent
+// along its longest axis divides by zero there (undefined); everything goes to bucket 0 here.
+size_t splitPrimitivesBySAHBin(const AABB& aabb, uint32_t axis, orc_primitive* primitives, size_t n)
+{
+    const size_t numBins = 10;
+    std::vector<std::vector<orc_primitive>> bins(numBins + 1);
+    const float binSize = (aabb.upper[(int)axis] - aabb.lower[(int)axis]) / numBins;
+    for (size_t k = 0; k < n; k++) {
+        const float q = std::floor((computePrimitiveCentroid(primitives[k])[(int)axis] - aabb.lower[(int)axis]) / binSize);
+        size_t binIndex = 0;
+        if (q >= 0.0f)
+            binIndex = q >= float(numBins) ? numBins : static_cast<size_t>(q);
+        bins[binIndex].push_back(primitives[k]);
+    }
+    size_t index = 0;
+    for (auto& bin : bins)
+        for (orc_primitive& primitive : bin)
+            primitives[index++] = primitive;
+
+    std::vector<float> costs(n - 2);
+    AABB leftAABB = computeSpanAABB(primitives, 1);
+    for (size_t i = 1; i < n - 1; i++) {
+        const float leftArea = computeSurfaceArea(leftAABB);
+        costs[i - 1] = (float)i * leftArea;
+        leftAABB = mergeAABBs(leftAABB, computePrimitiveAABB(primitives[i]));
+    }
+    AABB rightAABB = computeSpanAABB(primitives + (n - 1), 1);
+    for (size_t i = n - 2; i > 0; i--) {
+        const float rightArea = computeSurfaceArea(rightAABB);
+        costs[i - 1] += (float)(n - i) * rightArea;
+        rightAABB = mergeAABBs(rightAABB, computePrimitiveAABB(primitives[i]));
+    }
+    size_t optimalSplit = 0;
+    for (size_t i = 0; i < costs.size(); i++)
+        if (costs[i] < costs[optimalSplit])
+            optimalSplit = i;
+    return optimalSplit + 1;
+}
+
 struct Builder {
     std::vector<orc_node> nodes;
     std::vector<orc_primitive> out;
+    bool sahBinning = false;
     // src/bvh.cpp:424-493
     void buildRecursive(orc_primitive* prims, size_t n, uint32_t nodeIndex)
     {
@@ -376,7 +432,7 @@ struct Builder {
             return;
         }
         const uint32_t axis = computeAABBLongestAxis(aabb);
-        const size_t split = splitPrimitivesByMedian(axis, prims, n);
+        const size_t split = sahBinning ? splitPrimitivesBySAHBin(aabb, axis, prims, n) : splitPrimitivesByMedian(axis, prims, n);
         const uint32_t left = static_cast<uint32_t>(nodes.size());
         nodes.emplace_back();
         const uint32_t right = static_cast<uint32_t>(nodes.size());
@@ -959,10 +1015,9 @@ extern "C" {
 int orc_bvh_build(const orc_primitive* prims_in, uint32_t n, int sah_binning, orc_node* nodes_out,
     orc_primitive* prims_out, uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves)
 {
-    if (sah_binning)
-        return -1;
     std::vector<orc_primitive> prims(prims_in, prims_in + n);
     Builder b;
+    b.sahBinning = sah_binning != 0;
     b.out.reserve(n);
     b.nodes.reserve(n + 1);
     b.nodes.emplace_back(); // root

@@ -156,9 +156,9 @@ typedef struct {
 
 typedef struct orc_scene orc_scene;
 
-/* BVH::BVH (src/bvh.cpp:52-101) with the median split (src/bvh.cpp:208-223).
- * nodes_out needs capacity max(2, 2*n) entries, prims_out n entries.
- * Returns 0, or -1 for an unsupported request (SAH binning). */
+/* BVH::BVH (src/bvh.cpp:52-101) with the median split (src/bvh.cpp:208-223) or,
+ * sah_binning != 0, splitPrimitivesBySAHBin (src/extra.cpp:493-543).
+ * nodes_out needs capacity max(2, 2*n) entries, prims_out n entries.  Returns 0. */
 int orc_bvh_build(const orc_primitive* prims_in, uint32_t n, int sah_binning,
                   orc_node* nodes_out, orc_primitive* prims_out,
                   uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves);

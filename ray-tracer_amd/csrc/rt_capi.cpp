@@ -222,6 +222,69 @@ struct HostBuilder {
     std::vector<KeyIdx> scratch;
     std::vector<rt_node> nodes;
     std::vector<uint32_t> outOrder;
+    bool sahBinning = false;
+    std::vector<uint32_t> binOf, tmpOrder;
+    std::vector<float> costs;
+
+    static float area(const float* lo, const float* hi) // computeSurfaceArea, src/extra.cpp:475-483
+    {
+        const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return 2 * (x * y + x * z + y * z);
+    }
+
+    // splitPrimitivesBySAHBin, src/extra.cpp:493-543, on primitive indices: a counting sort into
+    // the reference's eleven buckets (stable, like its bucket-by-bucket copy back), its cost of
+    // every split position -- the right-hand box one primitive behind its count, as there -- and
+    // the first cheapest position.  No extent along the axis (a division by zero there): bucket 0.
+    uint32_t sahSplit(uint32_t begin, uint32_t n, int axis, const rt_node& node)
+    {
+        const size_t numBins = 10;
+        const float binSize = (node.upper[axis] - node.lower[axis]) / numBins;
+        uint32_t count[12] = {};
+        binOf.resize(n);
+        for (uint32_t i = 0; i < n; i++) {
+            const float q = std::floor((info[order[begin + i]].c[axis] - node.lower[axis]) / binSize);
+            uint32_t b = 0;
+            if (q >= 0.0f)
+                b = q >= float(numBins) ? static_cast<uint32_t>(numBins) : static_cast<uint32_t>(q);
+            binOf[i] = b;
+            count[b + 1]++;
+        }
+        for (int b = 0; b < 11; b++)
+            count[b + 1] += count[b];
+        tmpOrder.resize(n);
+        for (uint32_t i = 0; i < n; i++)
+            tmpOrder[count[binOf[i]]++] = order[begin + i];
+        std::copy(tmpOrder.begin(), tmpOrder.end(), order.begin() + begin);
+
+        costs.assign(n - 2, 0.0f);
+        float lo[3], hi[3];
+        auto start = [&](uint32_t k) {
+            const BuildPrim& p = info[order[begin + k]];
+            for (int a = 0; a < 3; a++)
+                lo[a] = p.lo[a], hi[a] = p.hi[a];
+        };
+        auto merge = [&](uint32_t k) {
+            const BuildPrim& p = info[order[begin + k]];
+            for (int a = 0; a < 3; a++)
+                lo[a] = std::min(lo[a], p.lo[a]), hi[a] = std::max(hi[a], p.hi[a]);
+        };
+        start(0);
+        for (uint32_t i = 1; i < n - 1; i++) {
+            costs[i - 1] = (float)i * area(lo, hi);
+            merge(i);
+        }
+        start(n - 1);
+        for (uint32_t i = n - 2; i > 0; i--) {
+            costs[i - 1] += (float)(n - i) * area(lo, hi);
+            merge(i);
+        }
+        uint32_t best = 0;
+        for (uint32_t i = 0; i < n - 2; i++)
+            if (costs[i] < costs[best])
+                best = i;
+        return best + 1;
+    }
 
     void build(uint32_t begin, uint32_t n, uint32_t nodeIndex)
     {
@@ -251,13 +314,18 @@ struct HostBuilder {
         }
         const float xl = node.upper[0] - node.lower[0], yl = node.upper[1] - node.lower[1], zl = node.upper[2] - node.lower[2];
         const int axis = (xl >= yl && xl >= zl) ? 0 : (yl >= zl ? 1 : 2); // src/bvh.cpp:183-196
-        scratch.resize(n);
-        for (uint32_t i = 0; i < n; i++)
-            scratch[i] = { info[order[begin + i]].c[axis], order[begin + i] };
-        std::sort(scratch.begin(), scratch.end(), [](const KeyIdx& a, const KeyIdx& b) { return a.key < b.key; });
-        for (uint32_t i = 0; i < n; i++)
-            order[begin + i] = scratch[i].idx;
-        const uint32_t split = (n + 1) / 2;
+        uint32_t split;
+        if (sahBinning) {
+            split = sahSplit(begin, n, axis, node);
+        } else {
+            scratch.resize(n);
+            for (uint32_t i = 0; i < n; i++)
+                scratch[i] = { info[order[begin + i]].c[axis], order[begin + i] };
+            std::sort(scratch.begin(), scratch.end(), [](const KeyIdx& a, const KeyIdx& b) { return a.key < b.key; });
+            for (uint32_t i = 0; i < n; i++)
+                order[begin + i] = scratch[i].idx;
+            split = (n + 1) / 2;
+        }
         const uint32_t left = static_cast<uint32_t>(nodes.size());
         nodes.emplace_back();
         const uint32_t right = static_cast<uint32_t>(nodes.size());
@@ -276,10 +344,9 @@ int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_n
 {
     if ((n && !prims_in) || !nodes_out || (n && !prims_out) || !n_nodes || !n_levels || !n_leaves)
         return fail(nullptr, RT_ERR_INVALID, "rt_bvh_build: NULL argument");
-    if (sah_binning)
-        return fail(nullptr, RT_ERR_UNSUPPORTED, "rt_bvh_build: SAH binning (enableBvhSahBinning) is outside this path");
     HostBuilder b;
     b.in = prims_in;
+    b.sahBinning = sah_binning != 0;
     b.info.resize(n);
     b.order.resize(n);
     for (uint32_t i = 0; i < n; i++) {
@@ -387,8 +454,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
             work.push_back({ nd.data[0], it.level + 1 });
         }
     }
-    if (maxLevel > (uint32_t)kMaxStack)
-        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: BVH has %u levels (max %d)", maxLevel, kMaxStack);
+    const uint32_t callerLevels = maxLevel; // only a limit when the caller's own inner nodes are traversed (below)
 
     auto childRef = [&](uint32_t child) -> uint32_t {
         const rt_node& c = nodes[child];
@@ -585,6 +651,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
         }
     }
     if (!ownTree) {
+        if (callerLevels > (uint32_t)kMaxStack)
+            return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: BVH has %u levels (max %d)", callerLevels, kMaxStack);
+        maxLevel = callerLevels;
         pairs.resize(innerOrder.size() * 2);
         for (size_t k = 0; k < innerOrder.size(); k++) {
             const rt_node& nd = nodes[innerOrder[k]];

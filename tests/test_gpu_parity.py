@@ -52,6 +52,38 @@ def test_bvh_intersection_matches_oracle(ctx, name, n):
         assert np.array_equal(h_o["material"], h_g["material"])
 
 
+@pytest.mark.parametrize("name", ["CornellBox", "Teapot"])
+def test_sah_binned_bvh_traverses_like_the_oracle(ctx, name):
+    """Features::extra.enableBvhSahBinning: the tree rt_bvh_build makes with splitPrimitivesBySAHBin,
+    uploaded and traversed; same hits as the oracle over the same tree, and a frame equal to the
+    median-split tree's (a closest hit does not depend on the tree)."""
+    scn = common.scene(name)
+    nodes, prims, _, _ = capi.bvh_build(scn.primitives(), sah_binning=True)
+    osc = orc.OracleScene(scn, nodes, prims)
+    ctx.upload_scene(scn, nodes, prims)
+    f = common.features(enableNormalInterp=1, enableTextureMapping=1)
+    rays = common.random_rays(2000)
+    r_o, h_o, _ = osc.intersect(f, rays)
+    ctx.set_features(f)
+    r_g, h_g = ctx.intersect(rays)
+    assert np.array_equal(h_o["hit"], h_g["hit"]) and h_o["hit"].sum() > 20
+    assert np.array_equal(r_o["t"].view(np.uint32), r_g["t"].view(np.uint32))
+    assert np.array_equal(h_o["primitive"], h_g["primitive"])
+    assert np.array_equal(h_o["normal"].view(np.uint32), h_g["normal"].view(np.uint32))
+    fr = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, numPixelSamples=2)
+    ctx.set_features(fr)
+    w, h = 96, 64
+    cam = sio.default_camera(w, h)
+    got, st = ctx.render(cam, w, h)
+    ctx.upload_scene(scn)  # median-split tree
+    ctx.set_features(fr)
+    ref, st2 = ctx.render(cam, w, h)
+    assert st["rays"] == st2["rays"]
+    assert common.image_error(got, ref)[0] <= 2e-5
+    want, so = osc.render(fr, cam, w, h, policy=0)
+    assert so["rays"] == st["rays"] and common.image_error(got, want)[0] <= 2e-5
+
+
 def test_pyramid_known_answers(ctx):
     """tests/bvh_tests.cpp:901-1008"""
     scn, _ = common.pyramid_scene()
