@@ -946,7 +946,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     const uint32_t stackEntries = std::max<uint32_t>(ctx->numLevels, 2) + 1; // one more for the bottom marker
     const size_t lds = static_cast<size_t>(stackEntries) * blockThreads * 4;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, sizeof(DevCounters), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, collect ? sizeof(DevCounters) : offsetof(DevCounters, waveLog), stream));
     if (timeIt) {
         if (ctx->evUsed + 5 > ctx->evPool.size()) {
             if (ctx->evPool.size() >= 5 * 4096) { // unread launches pile up: fold them by waiting once
@@ -1023,7 +1023,9 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             + nodesPerPixel * (64 + sizeof(NodeB) + (12ull + 48 + 1) * std::max(1u, slots));
         uint64_t batchSlots = ctx->workspaceCap / std::max<uint64_t>(1, bytesPerPixel);
         batchSlots = std::min<uint64_t>(batchSlots, 0x7fffffffull / wp.R);                                       // path index in 31 bits
-        const uint64_t nodeCap = 0xffffffffull / std::max(1u, slots); // item index (node * slots + slot) in 32 bits
+        // item index (node * slots + slot) in 32 bits, with room for the queue head to run past the end
+        // by one batch per wavefront
+        const uint64_t nodeCap = (0xffffffffull - (1ull << 26)) / std::max(1u, slots);
         if (nodeCap <= nodeSlack)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u light samples per hit exceed the supported count", slots);
         batchSlots = std::min<uint64_t>(batchSlots, (nodeCap - nodeSlack) / nodesPerPixel);
@@ -1098,8 +1100,9 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
 
 static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
 {
-    DevCounters c;
-    HIP_TRY(ctx, hipMemcpy(&c, ctx->dCounters, sizeof c, hipMemcpyDeviceToHost));
+    static DevCounters c; // large (per-wave log); calls on one context are not concurrent
+    const bool debug = getenv("RT_AMD_DEBUG_COUNTERS") != nullptr;
+    HIP_TRY(ctx, hipMemcpy(&c, ctx->dCounters, debug ? sizeof c : offsetof(DevCounters, waveLog), hipMemcpyDeviceToHost));
     if (getenv("RT_AMD_DEBUG_COUNTERS") && (c.loopIters[0][2] | c.loopIters[1][2])) {
         // wave iterations of the traversal loop and the mean number of lanes that had work in them
         const char* names[2] = { "path", "shadow" };
@@ -1113,6 +1116,25 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
                     names[k], double(c.cycles[k][0]) / c.cycles[k][3], wi > 0 ? c.cycles[k][0] / wi : 0.0, double(c.cycles[k][1]) / c.cycles[k][3],
                     wl > 0 ? c.cycles[k][1] / wl : 0.0, (double(c.cycles[k][2]) - c.cycles[k][0] - c.cycles[k][1]) / c.cycles[k][3],
                     1.0 - double(c.cycles[k][2]) / c.cycles[k][3]);
+            fprintf(stderr, "[rt_amd] %s: %llu waves traced rays; longest wave %.0f clocks, mean of all waves %.0f\n", names[k],
+                (unsigned long long)c.busyWaves[k], double(c.maxCycles[k]), wr > 0 ? double(c.cycles[k][3]) / double(std::max<unsigned long long>(1, c.busyWaves[k])) : 0.0);
+            { // when the waves of the kernel started and ended, in 10 ns ticks after the first start
+                std::vector<unsigned long long> st, en;
+                unsigned long long t0 = ~0ull;
+                for (int w = 0; w < 8192; w++)
+                    if (c.waveLog[k][w][1])
+                        t0 = std::min(t0, c.waveLog[k][w][0]);
+                for (int w = 0; w < 8192; w++)
+                    if (c.waveLog[k][w][1])
+                        st.push_back(c.waveLog[k][w][0] - t0), en.push_back(c.waveLog[k][w][1] - t0);
+                if (!st.empty()) {
+                    std::sort(st.begin(), st.end());
+                    std::sort(en.begin(), en.end());
+                    auto q = [](const std::vector<unsigned long long>& v, double f) { return (double)v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+                    fprintf(stderr, "[rt_amd] %s: %zu waves; start ticks p50 %.0f p90 %.0f max %.0f; end ticks p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f (10 ns each)\n",
+                        names[k], st.size(), q(st, 0.5), q(st, 0.9), (double)st.back(), q(en, 0.1), q(en, 0.5), q(en, 0.9), q(en, 0.99), (double)en.back());
+                }
+            }
             fprintf(stderr, "[rt_amd] %s: share of inner steps at pair records below 1024 / 2048 / 4096: %.3f %.3f %.3f (%u levels)\n", names[k],
                 li > 0 ? c.topHits[k][0] / li : 0.0, li > 0 ? c.topHits[k][1] / li : 0.0, li > 0 ? c.topHits[k][2] / li : 0.0, ctx->numLevels);
         }

@@ -173,6 +173,9 @@ struct DevCounters {
     unsigned long long loopIters[2][3]; // [0] path kernel, [1] shadow kernel
     unsigned long long topHits[2][3];   // inner steps at pair records below 1024 / 2048 / 4096
     unsigned long long cycles[2][4];    // shader clocks summed over waves: inner block, leaf block, run(), whole kernel
+    unsigned long long maxCycles[2], busyWaves[2]; // longest wave; waves that traced at least one ray
+    // counting launches only, not cleared otherwise: start and end clock of every wave of the two traversing kernels
+    unsigned long long waveLog[2][8192][2];
 };
 
 // ----------------------------------------------------------------------------

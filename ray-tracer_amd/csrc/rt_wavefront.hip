@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
     r.topHits[0] = r.topHits[1] = r.topHits[2] = 0;
     r.cycInner = r.cycLeaf = r.cycRun = 0;
     const long long tKernel = STATS ? clock64() : 0;
+    const long long tWall = STATS ? wall_clock64() : 0; // 100 MHz, the same on every XCD (the shader clock is not)
     uint32_t path = 0, item = 0, nrays = 0, made = 0;
     __shared__ uint32_t nodeBlkAll[4][2]; // per wave: next free slot and end of its block of node slots
     volatile __attribute__((address_space(3))) uint32_t* nodeBlk = (volatile __attribute__((address_space(3))) uint32_t*)nodeBlkAll[threadIdx.x >> 6];
@@ -331,6 +332,12 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
             atomicAdd(&ctr->cycles[0][1], r.cycLeaf);
             atomicAdd(&ctr->cycles[0][2], r.cycRun);
             atomicAdd(&ctr->cycles[0][3], (unsigned long long)(clock64() - tKernel));
+            atomicMax(&ctr->maxCycles[0], (unsigned long long)(clock64() - tKernel));
+            if (ir)
+                atomicAdd(&ctr->busyWaves[0], 1ull);
+            const uint32_t waveId = blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
+            if (waveId < 8192u)
+                ctr->waveLog[0][waveId][0] = (unsigned long long)tWall, ctr->waveLog[0][waveId][1] = (unsigned long long)wall_clock64();
         }
     }
 }
@@ -493,6 +500,7 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     r.topHits[0] = r.topHits[1] = r.topHits[2] = 0;
     r.cycInner = r.cycLeaf = r.cycRun = 0;
     const long long tKernel = STATS ? clock64() : 0;
+    const long long tWall = STATS ? wall_clock64() : 0; // 100 MHz, the same on every XCD (the shader clock is not)
     uint32_t item = 0;
     bool have = false, dead = false;
     WaveQueue q;
@@ -543,6 +551,12 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
             atomicAdd(&ctr->cycles[1][1], r.cycLeaf);
             atomicAdd(&ctr->cycles[1][2], r.cycRun);
             atomicAdd(&ctr->cycles[1][3], (unsigned long long)(clock64() - tKernel));
+            atomicMax(&ctr->maxCycles[1], (unsigned long long)(clock64() - tKernel));
+            if (ir)
+                atomicAdd(&ctr->busyWaves[1], 1ull);
+            const uint32_t waveId = blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
+            if (waveId < 8192u)
+                ctr->waveLog[1][waveId][0] = (unsigned long long)tWall, ctr->waveLog[1][waveId][1] = (unsigned long long)wall_clock64();
         }
     }
 }
