@@ -15,6 +15,13 @@ data-path collective), the only collective is the RCCL gather of the packed
 tile buffers to rank 0, which scatters them into Screen order.  The frame is
 the same whatever N is, so scaling is "strong".
 
+Frames in flight: consecutive steps go round-robin to `--in-flight` (default 3) contexts, each
+with its own stream, workspace and output buffers, the way a double- or triple-buffered
+renderer runs.  Every frame is still rendered, gathered and post-processed completely; the
+persistent traversal kernels of one frame merely start on the compute units the previous
+frame's kernels are draining from, which a single stream leaves idle.  `--in-flight 1` gives
+the one-frame-at-a-time latency.
+
 Rank 0 prints one JSON line.  value = rays of all ranks / wall time of the
 timed region (barrier + synchronize on both sides, max over ranks), rays being
 BVHInterface::intersect calls counted by the kernel.  The scene, BVH, lights
@@ -124,6 +131,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-scale", type=int, default=2)
+    ap.add_argument("--in-flight", type=int, default=3, help="frames in flight (contexts/streams used round-robin)")
     args = ap.parse_args()
 
     import torch
@@ -148,43 +156,58 @@ def main():
         desc += f" [resolution overridden to {width}x{height}]"
     camera = sio.default_camera(width, height)
 
-    ctx = capi.Context(local_rank)
-    ctx.upload_scene(scene)
-    ctx.set_features(features)
-
-    stream = torch.cuda.current_stream(dev)
-    sptr = stream.cuda_stream
+    lanes = max(1, args.in_flight)
     stride = capi.shard_floats(width, height, 0, world)
-    frame = torch.empty(width * height * 3, dtype=torch.float32, device=dev)
-    if world > 1:
-        packed = torch.zeros(stride, dtype=torch.float32, device=dev)
-        gathered = torch.empty((world, stride), dtype=torch.float32, device=dev) if rank == 0 else None
+    ctxs, streams, frames, packeds, gathereds = [], [], [], [], []
+    for _ in range(lanes):
+        c = capi.Context(local_rank)
+        c.upload_scene(scene)
+        c.set_features(features)
+        ctxs.append(c)
+        streams.append(torch.cuda.Stream(dev))
+        frames.append(torch.empty(width * height * 3, dtype=torch.float32, device=dev))
+        packeds.append(torch.zeros(stride, dtype=torch.float32, device=dev) if world > 1 else None)
+        gathereds.append(torch.empty((world, stride), dtype=torch.float32, device=dev) if world > 1 and rank == 0 else None)
+    ctx = ctxs[0]
 
-    def step():
-        if world == 1:
-            ctx.render_device(camera, width, height, frame.data_ptr(), frame.numel(), 0, 1, sptr)
-        else:
-            ctx.render_device(camera, width, height, packed.data_ptr(), packed.numel(), rank, world, sptr)
-            sharding.gather_packed(packed, rank, world, dist, gathered)
-            if rank == 0:
-                ctx.deinterleave(gathered.data_ptr(), width, height, world, frame.data_ptr(), sptr)
-                ctx.postprocess(frame.data_ptr(), width, height, sptr)  # bloom needs the whole frame (no-op when off)
+    def step(i):
+        k = i % lanes
+        c, frame = ctxs[k], frames[k]
+        with torch.cuda.stream(streams[k]):
+            sptr = streams[k].cuda_stream
+            if world == 1:
+                c.render_device(camera, width, height, frame.data_ptr(), frame.numel(), 0, 1, sptr)
+            else:
+                c.render_device(camera, width, height, packeds[k].data_ptr(), packeds[k].numel(), rank, world, sptr)
+                sharding.gather_packed(packeds[k], rank, world, dist, gathereds[k])
+                if rank == 0:
+                    c.deinterleave(gathereds[k].data_ptr(), width, height, world, frame.data_ptr(), sptr)
+                    c.postprocess(frame.data_ptr(), width, height, sptr)  # bloom needs the whole frame (no-op when off)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    def drain_stats():
+        tot = {"kernel_ms": 0.0, "path_ms": 0.0, "shadow_ms": 0.0, "launches": 0, "rays": 0}
+        for k in range(lanes):
+            st = ctxs[k].sync(streams[k].cuda_stream)
+            for key in ("kernel_ms", "path_ms", "shadow_ms", "launches"):
+                tot[key] += st[key]
+            tot["rays"] = max(tot["rays"], st["rays"])  # rays of one frame (the same on every lane)
+        return tot
+
+    for i in range(args.warmup):
+        step(i)
     fence()
-    ctx.sync(sptr)  # drop warm-up launches from the kernel-time sum
+    drain_stats()  # drop warm-up launches from the kernel-time sums
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    st = ctx.sync(sptr)  # rays of the last launch, summed kernel times of the timed launches
+    st = drain_stats()  # rays of one frame, summed kernel times of the timed launches
     nl = max(1, st["launches"])
     frame_ms, path_ms, shadow_ms = st["kernel_ms"] / nl, st["path_ms"] / nl, st["shadow_ms"] / nl
 
@@ -199,10 +222,15 @@ def main():
     else:
         dt_max, rays_total = dt, rays_local
 
+    # one frame on its own (outside the timed region): the kernels' durations when they do not share
+    # the compute units with a neighbouring frame's kernels
+    ctx.render_device(camera, width, height, (packeds[0] if world > 1 else frames[0]).data_ptr(),
+                      (packeds[0] if world > 1 else frames[0]).numel(), rank if world > 1 else 0, world, streams[0].cuda_stream)
+    alone = ctx.sync(streams[0].cuda_stream)
     # one more launch with the node / triangle counters on (outside the timed region)
-    tmp = packed if world > 1 else frame
-    cst = ctx.render_device(camera, width, height, tmp.data_ptr(), tmp.numel(), rank if world > 1 else 0, world, sptr,
-                            collect_stats=True)
+    tmp = packeds[0] if world > 1 else frames[0]
+    cst = ctx.render_device(camera, width, height, tmp.data_ptr(), tmp.numel(), rank if world > 1 else 0, world,
+                            streams[0].cuda_stream, collect_stats=True)
 
     if rank == 0:
         ms_per_step = dt_max / args.steps * 1e3
@@ -219,6 +247,7 @@ def main():
             k_rays, k_inner, k_tris = cst["rays"], cst["inner_nodes"], cst["tri_tests"]
         alg_bytes = 64.0 * k_inner + 36.0 * k_tris + 44.0 * k_rays
         alg_flops = 26.0 * (k_rays + 2.0 * k_inner) + 50.0 * k_tris
+        k_alone = (alone["shadow_ms"] if shadow_ms > 0 else alone["kernel_ms"]) / max(1, alone["launches"])
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         tflops = alg_flops / (k_ms * 1e-3) / 1e12
         traffic, traffic_src = measured_traffic(args.workload, kname, world, width, height)
@@ -229,11 +258,16 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "rays_per_frame": int(rays_total),
-                       "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)",
+                       "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)", "frames_in_flight": lanes,
                        "scene_note": "dragon.obj is absent from the reference snapshot; procedural stand-in with the same triangle count"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": round(k_ms, 4),
+                         "one_frame_alone": {"kernel_ms": round(k_alone, 4), "frame_device_ms": round(alone["kernel_ms"] / max(1, alone["launches"]), 4),
+                                             "achieved": round(alg_bytes / (k_alone * 1e-3) / 1e9, 2) if k_alone > 0 else None,
+                                             "frac": round(alg_bytes / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_alone > 0 else None,
+                                             "note": "with several frames in flight a launch shares the compute units with the neighbouring "
+                                                     "frames' kernels, so kernel_ms above is longer than the kernel takes on its own"},
                          "kernel_rays_per_launch": int(k_rays),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_ray": round(alg_bytes / max(1.0, k_rays), 2),
@@ -251,7 +285,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -90,6 +90,15 @@ struct WaveQueue {
     }
 };
 
+// Rays a wave takes from its queue per atomic: the configured batch when there is plenty of
+// work, less when the whole queue is only a few batches per wave (a shard of a frame on one of
+// many GPUs), so that the waves still finish close together; never below `least`.
+__device__ __forceinline__ uint32_t queueChunk(uint32_t total, uint32_t configured, uint32_t least)
+{
+    const uint32_t share = total / (gridDim.x * (blockDim.x / 64u) * 4u);
+    return share >= configured ? configured : (share < least ? least : share);
+}
+
 __device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
 {
     for (int off = 32; off > 0; off >>= 1)
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
     const Tracer<STATS> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = ctr->camQueued;
+    const uint32_t chunk = queueChunk(total, wp.chunkPath, 32u);
 
     RayState r;
     r.active = false;
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
         // ---- lanes without a path take the next queued camera ray
         for (int round = 0; round < 2; round++) {
             bool want = !have && !dead;
-            q.fetch(want, item, dead, &ctr->next, total, wp.chunkPath, lane);
+            q.fetch(want, item, dead, &ctr->next, total, chunk, lane);
             if (!have && !dead && !want) {
                 const float4 c0 = wb.camRays[2u * (size_t)item + 0], c1 = wb.camRays[2u * (size_t)item + 1];
                 path = __float_as_uint(c0.w);
@@ -489,6 +499,7 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nNodesAll = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
     const uint32_t total = ft.shadows ? nNodesAll * wp.slots : 0u; // shadows off: no ray at all (src/light.cpp:270-272)
+    const uint32_t chunk = queueChunk(total, wp.chunk, 64u);
 
     RayState r;
     r.active = false;
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
 
     for (;;) {
         bool want = !have && !dead;
-        q.fetch(want, item, dead, &ctr->nextShadow, total, wp.chunk, lane);
+        q.fetch(want, item, dead, &ctr->nextShadow, total, chunk, lane);
         if (!have && !dead && !want) {
             const float4* sr = wb.srays + 3u * (size_t)item;
             const float4 a = sr[0], b = sr[1];
