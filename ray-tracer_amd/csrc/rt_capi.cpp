@@ -56,6 +56,7 @@ struct rt_ctx {
     rt_light* dLights = nullptr;
     uint32_t lightCap = 0;
     std::vector<rt_light> hostLights;
+    bool anyMirror = true, anyClear = true, anyMirrorAndClear = true; // what the scene's materials can ask of a hit
     DevCounters* dCounters = nullptr;
     float* dFrame = nullptr;
     size_t frameCap = 0;
@@ -728,6 +729,14 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
     for (uint32_t i = 0; i < n_images; i++)
         std::memcpy(texels.data() + texs[i].offset, images[i].pixels, static_cast<size_t>(images[i].width) * images[i].height * 12);
 
+    ctx->anyMirror = ctx->anyClear = ctx->anyMirrorAndClear = false;
+    for (const DevMaterial& m : mats) {
+        const bool mirror = !(m.ks[0] == 0.0f && m.ks[1] == 0.0f && m.ks[2] == 0.0f), clear = m.transparency != 1.0f;
+        ctx->anyMirror |= mirror;
+        ctx->anyClear |= clear;
+        ctx->anyMirrorAndClear |= mirror && clear;
+    }
+
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, uploadVec(&ctx->dPairs, pairs));
@@ -966,7 +975,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     }
 
     const rt_features& F = ctx->features;
-    const bool perPixel = ctx->forcePerPixel || F.enableTransparency || (F.enableGlossyReflection && F.enableReflections);
+    const bool perPixel = ctx->forcePerPixel || (F.enableGlossyReflection && F.enableReflections);
     if (perPixel) {
         int variant = 0;
         if (F.enableTransparency)
@@ -1008,7 +1017,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
         const bool dof = F.enableDepthOfField != 0;
         int pathPerCU = 0, shadowPerCU = 0;
-        HIP_TRY(ctx, wavefrontOccupancy(collect, blockThreads, lds, &pathPerCU, &shadowPerCU));
+        const bool transp = F.enableTransparency != 0;
+        HIP_TRY(ctx, wavefrontOccupancy(collect, transp, blockThreads, lds, &pathPerCU, &shadowPerCU));
         if (pathPerCU < 1 || shadowPerCU < 1)
             return fail(ctx, RT_ERR_DEVICE, "render: the traversing kernels do not fit a compute unit (%zu B of LDS)", lds);
         pathPerCU = std::min(pathPerCU, 8), shadowPerCU = std::min(shadowPerCU, 8);
@@ -1018,7 +1028,16 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         }
         // every wavefront of the path kernel may leave part of its last block of node slots unused
         const uint64_t nodeSlack = static_cast<uint64_t>(ctx->numCU) * pathPerCU * (blockThreads / 64) * kNodeBlock;
-        const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * (F.enableReflections ? F.maxRayDepth + 1 : 1);
+        // Hits one camera ray can make.  A hit below the depth cap has a mirror child if its material
+        // has a ks, and with transparency a pass-through child if the material is not opaque
+        // (src/recursive.cpp:43-63): a chain of maxRayDepth + 1 hits, unless some material asks for both.
+        const bool mirrors = F.enableReflections && ctx->anyMirror, passes = transp && ctx->anyClear;
+        uint64_t nodesPerPath = 1;
+        if (mirrors && passes && ctx->anyMirrorAndClear)
+            nodesPerPath = (2ull << F.maxRayDepth) - 1;
+        else if (mirrors || passes)
+            nodesPerPath = static_cast<uint64_t>(F.maxRayDepth) + 1;
+        const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * nodesPerPath;
         const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + 32 + (F.enableEnvironmentMap ? 12 : 0))
             + nodesPerPixel * (64 + sizeof(NodeB) + (12ull + 48 + 1) * std::max(1u, slots));
         uint64_t batchSlots = ctx->workspaceCap / std::max<uint64_t>(1, bytesPerPixel);
@@ -1081,7 +1100,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                 marks = &ctx->evPool[ctx->evUsed + 1];
                 ctx->evHasMarks[ctx->evUsed / 5] = 1;
             }
-            HIP_TRY(ctx, launchWavefront(dof, collect, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
+            HIP_TRY(ctx, launchWavefront(dof, collect, transp, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
                               wb, ctx->dCounters, dOut, traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB),
                               traceKnobs(ctx->minActiveShadow, ctx->parkAShadow, ctx->parkBShadow), marks, ctx->numCU));
         }

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
 #else
 #define RT_PATH_ATTR
 #endif
-template <bool STATS>
+template <bool STATS, bool TRANSP>
 __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
@@ -203,7 +203,14 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
     volatile __attribute__((address_space(3))) uint32_t* nodeBlk = (volatile __attribute__((address_space(3))) uint32_t*)nodeBlkAll[threadIdx.x >> 6];
     if (lane == 0)
         nodeBlk[0] = nodeBlk[1] = 0u;
+    // With transparency a hit can have two children.  The mirror child is followed first, like
+    // renderRay does; the hit itself waits on this per-lane stack (entry-major in LDS) for its
+    // pass-through ray, which is rebuilt from the hit's record when its turn comes.
+    __shared__ uint32_t waitingAll[TRANSP ? (kMaxDepth + 1) * 256 : 1];
+    uint32_t* waiting = waitingAll + (TRANSP ? threadIdx.x : 0u);
+    int nWaiting = 0;
     int depth = 0, prev = -1, count = 0;
+    bool viaPass = false; // the ray in flight is the pass-through child of `prev` (else its mirror child)
     bool have = false, dead = false;
     WaveQueue q;
 
@@ -222,12 +229,15 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
                 have = true;
                 depth = 0;
                 prev = -1;
+                viaPass = false;
                 count = 0;
+                nWaiting = 0;
             }
-            // ---- paths whose ray has finished: record the hit, continue the chain or retire
+            // ---- paths whose ray has finished: record the hit, go on with a child ray or retire
             while (have && !r.active) {
                 if (sc.nSpheres)
                     tracer.spheres(r);
+                bool childLaunched = false;
                 if (r.hitPrim == kHitNone) { // src/recursive.cpp:29-32
                     const f3 env = sampleEnvironmentMap(sc, ft, r.d);
                     if (depth == 0) {
@@ -239,70 +249,105 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
                         }
                     } else {
                         NodeB& pb = wb.nodeB[prev];
-                        pb.child = kChildMiss;
-                        pb.cv[0] = env.x, pb.cv[1] = env.y, pb.cv[2] = env.z;
+                        if (viaPass) {
+                            pb.childP = kChildMiss;
+                            pb.cvP[0] = env.x, pb.cvP[1] = env.y, pb.cvP[2] = env.z;
+                        } else {
+                            pb.childR = kChildMiss;
+                            pb.cvR[0] = env.x, pb.cvR[1] = env.y, pb.cvR[2] = env.z;
+                        }
                     }
-                    wb.pathCount[path] = (uint8_t)count;
-                    have = false;
-                    break;
-                }
-                const HitCtx h = shadeHit(sc, ft, r);
-                // One node per shaded hit.  Every wave owns a block of kNodeBlock consecutive slots of
-                // the pool and hands them out itself; only a new block costs an atomic (one address
-                // takes well under a hundred of them per microsecond, far fewer than there are hits).
-                const unsigned long long am = __ballot(true);
-                const uint32_t n = (uint32_t)__popcll(am), rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
-                // (kept in LDS: only some lanes are here, all of the wave must see the update)
-                const uint32_t nodeCur = nodeBlk[0], nodeEnd = nodeBlk[1];
-                const uint32_t rem = nodeEnd - nodeCur;
-                uint32_t fresh = 0;
-                if (n > rem) {
-                    const int leader = __builtin_ctzll(am);
-                    if (lane == (uint32_t)leader)
-                        fresh = atomicAdd(&ctr->nodes, kNodeBlock);
-                    fresh = __shfl(fresh, leader);
-                }
-                const uint32_t idx = rank < rem ? nodeCur + rank : fresh + (rank - rem);
-                if (rank == 0) {
-                    nodeBlk[0] = n > rem ? fresh + (n - rem) : nodeCur + n;
-                    if (n > rem)
-                        nodeBlk[1] = fresh + kNodeBlock;
-                }
-                made++;
-                if (idx >= wb.maxNodes) { // cannot happen: the pool holds the worst case of the batch
-                    wb.pathCount[path] = (uint8_t)count;
-                    have = false;
-                    break;
-                }
-                float4* a = wb.nodeA + 4u * (size_t)idx;
-                a[0] = make_float4(h.P.x, h.P.y, h.P.z, h.N.x);
-                a[1] = make_float4(h.N.y, h.N.z, r.d.x, r.d.y);
-                a[2] = make_float4(r.d.z, h.kd.x, h.kd.y, h.kd.z);
-                a[3] = make_float4(h.ks.x, h.ks.y, h.ks.z, h.shin);
-                NodeB nb;
-                nb.path = path;
-                nb.depth = depth;
-                nb.child = kChildNone;
-                nb.cv[0] = nb.cv[1] = nb.cv[2] = 0.0f;
-                nb.pad[0] = nb.pad[1] = 0u;
-                wb.nodeB[idx] = nb;
-                if (depth == 0)
-                    wb.pathHead[path] = (int32_t)idx;
-                else
-                    wb.nodeB[prev].child = (int32_t)idx;
-                count++;
-                const bool reflective = !(h.ks.x == 0.0f && h.ks.y == 0.0f && h.ks.z == 0.0f);
-                if (depth < ft.maxDepth && ft.reflections && reflective) { // src/recursive.cpp:43-50
-                    f3 o, d;
-                    reflectionRay(h.P, r.d, h.N, o, d);
-                    tracer.launch(r, o, d, kFltMax, K_RADIANCE);
-                    nrays++;
-                    prev = (int)idx;
-                    depth++;
                 } else {
-                    wb.pathCount[path] = (uint8_t)count;
-                    have = false;
-                    break;
+                    const HitCtx h = shadeHit(sc, ft, r);
+                    // One node per shaded hit.  Every wave owns a block of kNodeBlock consecutive slots of
+                    // the pool and hands them out itself; only a new block costs an atomic (one address
+                    // takes well under a hundred of them per microsecond, far fewer than there are hits).
+                    const unsigned long long am = __ballot(true);
+                    const uint32_t n = (uint32_t)__popcll(am), rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+                    // (kept in LDS: only some lanes are here, all of the wave must see the update)
+                    const uint32_t nodeCur = nodeBlk[0], nodeEnd = nodeBlk[1];
+                    const uint32_t rem = nodeEnd - nodeCur;
+                    uint32_t fresh = 0;
+                    if (n > rem) {
+                        const int leader = __builtin_ctzll(am);
+                        if (lane == (uint32_t)leader)
+                            fresh = atomicAdd(&ctr->nodes, kNodeBlock);
+                        fresh = __shfl(fresh, leader);
+                    }
+                    const uint32_t idx = rank < rem ? nodeCur + rank : fresh + (rank - rem);
+                    if (rank == 0) {
+                        nodeBlk[0] = n > rem ? fresh + (n - rem) : nodeCur + n;
+                        if (n > rem)
+                            nodeBlk[1] = fresh + kNodeBlock;
+                    }
+                    if (idx < wb.maxNodes) { // always: the pool holds the worst case of the batch
+                        made++;
+                        float4* a = wb.nodeA + 4u * (size_t)idx;
+                        a[0] = make_float4(h.P.x, h.P.y, h.P.z, h.N.x);
+                        a[1] = make_float4(h.N.y, h.N.z, r.d.x, r.d.y);
+                        a[2] = make_float4(r.d.z, h.kd.x, h.kd.y, h.kd.z);
+                        a[3] = make_float4(h.ks.x, h.ks.y, h.ks.z, h.shin);
+                        NodeB nb;
+                        nb.path = path;
+                        nb.ordinal = (uint32_t)count;
+                        nb.depth = depth;
+                        nb.childR = nb.childP = kChildNone;
+                        nb.cvR[0] = nb.cvR[1] = nb.cvR[2] = 0.0f;
+                        nb.cvP[0] = nb.cvP[1] = nb.cvP[2] = 0.0f;
+                        nb.tr = h.tr;
+                        nb.mkd[0] = h.mkd.x, nb.mkd[1] = h.mkd.y, nb.mkd[2] = h.mkd.z;
+                        nb.pad = 0u;
+                        wb.nodeB[idx] = nb;
+                        if (depth == 0)
+                            wb.pathHead[path] = (int32_t)idx;
+                        else if (viaPass)
+                            wb.nodeB[prev].childP = (int32_t)idx;
+                        else
+                            wb.nodeB[prev].childR = (int32_t)idx;
+                        count++;
+                        if (depth < ft.maxDepth) { // src/recursive.cpp:43-63
+                            const bool reflective = !(h.ks.x == 0.0f && h.ks.y == 0.0f && h.ks.z == 0.0f);
+                            const bool wantRefl = ft.reflections && reflective;
+                            const bool wantPass = TRANSP && ft.transparency && h.tr != 1.0f;
+                            if (wantRefl) {
+                                if (wantPass)
+                                    waiting[256 * nWaiting++] = idx;
+                                f3 o, d;
+                                reflectionRay(h.P, r.d, h.N, o, d);
+                                tracer.launch(r, o, d, kFltMax, K_RADIANCE);
+                                viaPass = false;
+                                childLaunched = true;
+                            } else if (wantPass) { // generatePassthroughRay, src/recursive.cpp:98-111
+                                const f3 rd = r.d;
+                                tracer.launch(r, h.P + rd * 1.0e-5f, rd, kFltMax, K_RADIANCE);
+                                viaPass = true;
+                                childLaunched = true;
+                            }
+                            if (childLaunched) {
+                                nrays++;
+                                prev = (int)idx;
+                                depth++;
+                            }
+                        }
+                    }
+                }
+                if (!childLaunched) {
+                    // this branch of the ray tree is done: the deepest hit still waiting gets its pass-through ray
+                    if (TRANSP && nWaiting > 0) {
+                        const uint32_t w = waiting[256 * --nWaiting];
+                        const float4* a = wb.nodeA + 4u * (size_t)w;
+                        const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+                        const f3 P = { a0.x, a0.y, a0.z }, rd = { a1.z, a1.w, a2.x };
+                        depth = wb.nodeB[w].depth + 1;
+                        prev = (int)w;
+                        viaPass = true;
+                        tracer.launch(r, P + rd * 1.0e-5f, rd, kFltMax, K_RADIANCE);
+                        nrays++;
+                    } else {
+                        wb.pathCount[path] = (uint8_t)count;
+                        have = false;
+                        break;
+                    }
                 }
             }
             if (__ballot(!have && !dead) == 0ull)
@@ -411,7 +456,7 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
         // (the loop runs the same for every lane, so the lights are read through the scalar cache)
         int l = -1;
         uint32_t slot = 0, drawPrefix = 0, perSample = 0;
-        uint32_t node = 0, path = 0, depth = 0;
+        uint32_t node = 0, path = 0, ordinal = 0;
         bool live = false;
         if (item < total) {
             node = item / wp.slots;
@@ -426,8 +471,8 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
                 first += n;
                 draws += n * per;
             }
-            const uint2 pd = *reinterpret_cast<const uint2*>(&wb.nodeB[node]); // path, depth
-            path = pd.x, depth = pd.y;
+            const uint2 po = *reinterpret_cast<const uint2*>(&wb.nodeB[node]); // path, ordinal
+            path = po.x, ordinal = po.y;
             live = l >= 0 && path != kDeadNode;
             if (!live) { // a slot no hit was written to: no ray, no light
                 float4* sr = wb.srays + 3u * (size_t)item;
@@ -458,7 +503,7 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
                 int px, py;
                 slotToPixel(fr, wp.slotBegin + path / wp.R, px, py);
                 const uint32_t seed = (uint32_t)(fr.height * px + py);
-                const uint32_t hitOrdinal = wb.pathBase[path] + depth;
+                const uint32_t hitOrdinal = wb.pathBase[path] + ordinal;
                 uint32_t s = lcgSkip(seed, wp.mainStart + wp.drawsPerHit * hitOrdinal + drawPrefix + slot * perSample);
                 f3 pos, col;
                 if (light.type == 0) {
@@ -490,7 +535,10 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
     }
 }
 
-template <bool STATS>
+// TRANSP: testVisibilityLightSampleTransparency (src/light.cpp:112-151) instead of the binary
+// test: the closest hit along the ray; a hit short of the shaded point on a material that is
+// not opaque tints the light and the ray goes on from there.
+template <bool STATS, bool TRANSP>
 __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
@@ -512,9 +560,11 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     r.cycInner = r.cycLeaf = r.cycRun = 0;
     const long long tKernel = STATS ? clock64() : 0;
     const long long tWall = STATS ? wall_clock64() : 0; // 100 MHz, the same on every XCD (the shader clock is not)
-    uint32_t item = 0;
+    uint32_t item = 0, extra = 0;
     bool have = false, dead = false;
     WaveQueue q;
+    f3 curKd = mk3(0.0f); // TRANSP: kd of the last surface the light went through, and the product of
+    float tprod = 1.0f;   // the transparencies on the way
 
     for (;;) {
         bool want = !have && !dead;
@@ -523,18 +573,54 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
             const float4* sr = wb.srays + 3u * (size_t)item;
             const float4 a = sr[0], b = sr[1];
             if (a.w >= 0.0f) { // a negative length marks the slot of a node that holds no hit
-                tracer.launch(r, { a.x, a.y, a.z }, { b.x, b.y, b.z }, a.w, K_SHADOW_ANY);
+                tracer.launch(r, { a.x, a.y, a.z }, { b.x, b.y, b.z }, a.w, TRANSP ? K_SHADOW_CLOSEST : K_SHADOW_ANY);
                 have = true;
+                if (TRANSP) {
+                    curKd = ld3(wb.nodeB[item / wp.slots].mkd); // src/light.cpp:126
+                    tprod = 1.0f;
+                }
             }
         }
         if (have && !r.active) {
             if (sc.nSpheres)
                 tracer.spheres(r);
-            // src/light.cpp:101-107
-            const bool visible = (r.hitPrim == kHitNone) ? true : (fabsf(r.tmax - r.slen) <= 0.0001f);
-            if (!visible)
-                wb.svis[item] = 0;
-            have = false;
+            if (!TRANSP) {
+                // src/light.cpp:101-107
+                const bool visible = (r.hitPrim == kHitNone) ? true : (fabsf(r.tmax - r.slen) <= 0.0001f);
+                if (!visible)
+                    wb.svis[item] = 0;
+                have = false;
+            } else { // src/light.cpp:138-150
+                const float4 a0 = wb.nodeA[4u * (size_t)(item / wp.slots)];
+                const f3 P = { a0.x, a0.y, a0.z };
+                const f3 hp = r.o + r.tmax * r.d;
+                const bool atPoint = allEpsEq(hp, P, 0.0001f);
+                bool again = false;
+                if (r.hitPrim != kHitNone && !atPoint) {
+                    const DevMaterial hm = r.hitPrim >= 0 ? sc.mats[__float_as_uint(sc.attrs[4u * (uint32_t)r.hitPrim + 3u].w)]
+                                                          : sc.mats[sc.spheres[-2 - r.hitPrim].material];
+                    if (hm.transparency != 1.0f) {
+                        curKd = ld3(hm.kd);
+                        tprod *= hm.transparency;
+                        again = true;
+                    }
+                }
+                if (again) {
+                    const f3 d = r.d;
+                    tracer.launch(r, hp + d * 1.0e-5f, d, kFltMax, K_SHADOW_CLOSEST); // src/recursive.cpp:98-111
+                    extra++;
+                } else {
+                    float4* sr = wb.srays + 3u * (size_t)item;
+                    if (atPoint) {
+                        const float4 c = sr[2];
+                        const f3 v = mk3(c.x, c.y, c.z) * curKd * tprod;
+                        sr[2] = make_float4(v.x, v.y, v.z, 0.0f);
+                    } else {
+                        wb.svis[item] = 0;
+                    }
+                    have = false;
+                }
+            }
         }
         if (__ballot(have) == 0ull) {
             if (__ballot(!dead) == 0ull)
@@ -547,7 +633,12 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     const unsigned long long ni = waveSum(r.nInner), nt = waveSum(r.nTris);
     const unsigned long long ii = waveSum(r.itInner), il = waveSum(r.itLeaf), ir = waveSum(r.itRuns);
     const unsigned long long th[3] = { waveSum(r.topHits[0]), waveSum(r.topHits[1]), waveSum(r.topHits[2]) };
+    const unsigned long long nx = TRANSP ? waveSum(extra) : 0ull;
     if (lane == 0) {
+        if (TRANSP && nx) { // the rays that went on through a surface; the first ray of every sample is counted where it is made
+            atomicAdd(&ctr->rays, nx);
+            atomicAdd(&ctr->sRays, nx);
+        }
         if (STATS) {
             atomicAdd(&ctr->inner, ni);
             atomicAdd(&ctr->tris, nt);
@@ -587,8 +678,12 @@ __global__ __launch_bounds__(256) void shadowShadeKernel(const DevScene sc, cons
             const uint32_t node = item / wp.slots;
             const float4* a = wb.nodeA + 4u * (size_t)node;
             const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-            const f3 N = { a0.w, a1.x, a1.y }, rd = { a1.z, a1.w, a2.x }, kd = { a2.y, a2.z, a2.w }, ks = { a3.x, a3.y, a3.z };
-            c = computeShading(ft, N, kd, ks, a3.w, -rd, -mk3(d.x, d.y, d.z), vis);
+            f3 N = { a0.w, a1.x, a1.y };
+            const f3 rd = { a1.z, a1.w, a2.x }, kd = { a2.y, a2.z, a2.w }, ks = { a3.x, a3.y, a3.z };
+            const f3 l = -mk3(d.x, d.y, d.z);
+            if (ft.transparency && wb.nodeB[node].tr < 1.0f && dot(N, l) < 0.0f) // src/light.cpp:174-176: lit from behind
+                N = -N;
+            c = computeShading(ft, N, kd, ks, a3.w, -rd, l, vis);
         }
         float* dst = wb.contrib + 3u * (size_t)item;
         dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
@@ -631,9 +726,9 @@ __device__ __forceinline__ f3 pathValue(const DevScene& sc, const DevFeat& ft, c
     f3 cv = mk3(0.0f);
     while (n <= kMaxDepth) {
         chain[n++] = cur;
-        const NodeB nb = wb.nodeB[cur];
-        link = nb.child;
-        cv = ld3(nb.cv);
+        const NodeB& nb = wb.nodeB[cur];
+        link = nb.childR;
+        cv = ld3(nb.cvR);
         if (link < 0)
             break;
         cur = link;
@@ -651,9 +746,70 @@ __device__ __forceinline__ f3 pathValue(const DevScene& sc, const DevFeat& ft, c
     return v;
 }
 
+// The same with transparency: a tree of hits, evaluated like the recursion does (src/recursive.cpp:43-63):
+// a hit's own light, plus its mirror child times ks, then blended with its pass-through child.
+__device__ __forceinline__ f3 pathValueTree(const DevScene& sc, const DevFeat& ft, const WfParams& wp, const WfBuffers& wb, uint32_t path)
+{
+    const int32_t head = wb.pathHead[path];
+    if (head == kPathMiss)
+        return ft.envMap ? ld3(wb.pathEnv + 3u * path) : mk3(0.0f);
+    int32_t nodeAt[kMaxDepth + 1];
+    int stage[kMaxDepth + 1]; // 0 new, 1 waiting for the mirror child, 2 waiting for the pass-through child
+    f3 acc[kMaxDepth + 1];
+    int sp = 0;
+    nodeAt[0] = head;
+    stage[0] = 0;
+    f3 ret = mk3(0.0f);
+    for (;;) {
+        const uint32_t n = (uint32_t)nodeAt[sp];
+        const NodeB& nb = wb.nodeB[n];
+        const int st = stage[sp];
+        bool passNext = false;
+        if (st == 0) {
+            acc[sp] = nodeLo(sc, ft, wb, n, wp.slots);
+            const int32_t cr = nb.childR;
+            if (cr >= 0 && sp < kMaxDepth) {
+                stage[sp] = 1;
+                sp++;
+                nodeAt[sp] = cr;
+                stage[sp] = 0;
+                continue;
+            }
+            if (cr == kChildMiss) {
+                const float4 a3 = wb.nodeA[4u * (size_t)n + 3];
+                acc[sp] = acc[sp] + ld3(nb.cvR) * mk3(a3.x, a3.y, a3.z);
+            }
+            passNext = true;
+        } else if (st == 1) { // src/recursive.cpp:126
+            const float4 a3 = wb.nodeA[4u * (size_t)n + 3];
+            acc[sp] = acc[sp] + ret * mk3(a3.x, a3.y, a3.z);
+            passNext = true;
+        }
+        if (passNext) {
+            const int32_t cp = nb.childP;
+            if (cp >= 0 && sp < kMaxDepth) {
+                stage[sp] = 2;
+                sp++;
+                nodeAt[sp] = cp;
+                stage[sp] = 0;
+                continue;
+            }
+            const float tr = nb.tr;
+            ret = (cp == kChildMiss) ? (ld3(nb.cvP) * tr) + (acc[sp] * (1.0f - tr)) : acc[sp];
+        } else { // src/recursive.cpp:142
+            const float tr = nb.tr;
+            ret = (ret * tr) + (acc[sp] * (1.0f - tr));
+        }
+        if (sp == 0)
+            return ret;
+        sp--;
+    }
+}
+
 // One lane per camera ray evaluates its chain (the chains of a pixel sit all over the node
 // pool, so their latencies overlap instead of queueing up in one lane); the first lane of
 // each pixel then adds the pixel's values in ray order, exactly as renderRays does.
+template <bool TRANSP>
 __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp,
     const WfBuffers wb, float* __restrict__ out)
 {
@@ -669,7 +825,7 @@ __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const De
         const uint32_t i = base + j;
         f3 v = mk3(0.0f);
         if (valid && i < wp.R)
-            v = pathValue(sc, ft, wp, wb, s * wp.R + i);
+            v = TRANSP ? pathValueTree(sc, ft, wp, wb, s * wp.R + i) : pathValue(sc, ft, wp, wb, s * wp.R + i);
         vals[3u * threadIdx.x + 0] = v.x;
         vals[3u * threadIdx.x + 1] = v.y;
         vals[3u * threadIdx.x + 2] = v.z;
@@ -696,18 +852,28 @@ __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const De
 // ---------------------------------------------------------------------------
 typedef void (*ShadowFn)(const DevScene, const DevFeat, const WfParams, const WfBuffers, DevCounters*, int);
 
-static ShadowFn pathVariant(bool stats) { return stats ? pathKernel<true> : pathKernel<false>; }
-static ShadowFn shadowVariant(bool stats) { return stats ? shadowTraceKernel<true> : shadowTraceKernel<false>; }
-
-hipError_t wavefrontOccupancy(bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks)
+static ShadowFn pathVariant(bool stats, bool transp)
 {
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(pathBlocks, pathVariant(stats), blockThreads, ldsBytes);
-    if (e != hipSuccess)
-        return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(shadowBlocks, shadowVariant(stats), blockThreads, ldsBytes);
+    if (transp)
+        return stats ? pathKernel<true, true> : pathKernel<false, true>;
+    return stats ? pathKernel<true, false> : pathKernel<false, false>;
+}
+static ShadowFn shadowVariant(bool stats, bool transp)
+{
+    if (transp)
+        return stats ? shadowTraceKernel<true, true> : shadowTraceKernel<false, true>;
+    return stats ? shadowTraceKernel<true, false> : shadowTraceKernel<false, false>;
 }
 
-hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
+hipError_t wavefrontOccupancy(bool stats, bool transp, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks)
+{
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(pathBlocks, pathVariant(stats, transp), blockThreads, ldsBytes);
+    if (e != hipSuccess)
+        return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(shadowBlocks, shadowVariant(stats, transp), blockThreads, ldsBytes);
+}
+
+hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
     const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU)
 {
@@ -717,7 +883,7 @@ hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlock
         hipLaunchKernelGGL(cameraKernel<true>, dim3(cb), dim3(256), 0, stream, sc, cam, ft, fr, wp, wb, ctr);
     else
         hipLaunchKernelGGL(cameraKernel<false>, dim3(cb), dim3(256), 0, stream, sc, cam, ft, fr, wp, wb, ctr);
-    hipLaunchKernelGGL(pathVariant(stats), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActive);
+    hipLaunchKernelGGL(pathVariant(stats, transp), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActive);
     if (marks)
         (void)hipEventRecord(marks[0], stream);
     const int pb = (int)((wp.nSlots + 255) / 256);
@@ -725,12 +891,16 @@ hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlock
     hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr, sc.lights);
     if (marks)
         (void)hipEventRecord(marks[1], stream);
-    hipLaunchKernelGGL(shadowVariant(stats), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
+    hipLaunchKernelGGL(shadowVariant(stats, transp), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
     if (marks)
         (void)hipEventRecord(marks[2], stream);
     hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
-    hipLaunchKernelGGL(combineKernel, dim3((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock), dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
+    const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
+    if (transp)
+        hipLaunchKernelGGL(combineKernel<true>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
+    else
+        hipLaunchKernelGGL(combineKernel<false>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
     return hipGetLastError();
 }
 

@@ -6,14 +6,22 @@
 
 namespace rt {
 
-// One shaded hit.  A: what shading needs.  B: links and bookkeeping.
+// One shaded hit.  A: what shading needs.  B: links and bookkeeping.  The hits of a camera
+// ray form a tree: every hit may have a mirror child and, with transparency on, a pass-through
+// child (src/recursive.cpp:43-63).
 struct NodeB {
-    uint32_t path; // path index inside the batch
-    int32_t depth;
-    int32_t child; // kChildNone, kChildMiss (value in cv), or node index
-    float cv[3];
-    uint32_t pad[2];
+    uint32_t path;    // path index inside the batch
+    uint32_t ordinal; // position of the hit among its camera ray's hits in the order renderRay visits them
+    int32_t depth;    // rayDepth of the ray that made the hit
+    int32_t childR;   // mirror child: kChildNone, kChildMiss (its value in cvR), or node index
+    int32_t childP;   // pass-through child, likewise (cvP)
+    float cvR[3];
+    float cvP[3];
+    float tr;         // material transparency
+    float mkd[3];     // material kd (not the texture's): where the transparent shadow test starts, src/light.cpp:126
+    uint32_t pad;
 };
+static_assert(sizeof(NodeB) == 64, "NodeB is one 64-B record");
 constexpr int32_t kChildNone = -1, kChildMiss = -2;
 constexpr int32_t kPathMiss = -1;
 constexpr uint32_t kDeadNode = 0xffffffffu; // NodeB::path of a pool slot no hit was written to
@@ -46,8 +54,8 @@ struct WfParams {
     uint32_t validPaths; // camera rays of the batch's real (non-padding) pixels
 };
 
-hipError_t wavefrontOccupancy(bool stats, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
-hipError_t launchWavefront(bool dof, bool stats, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
+hipError_t wavefrontOccupancy(bool stats, bool transp, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
+hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
     const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
 
