@@ -158,7 +158,9 @@ typedef struct {
                              stats read, summed; HIP events on the launch stream */
     float total_ms;       /* wall time of the call */
     uint32_t launches;    /* render launches kernel_ms covers */
-    uint32_t reserved;
+    uint32_t batches;     /* pixel batches of those launches (wavefront path): path_ms and shadow_ms
+                             sum over them; a frame whose working set exceeds the workspace is
+                             rendered in several */
     /* the share of the shadow-ray kernel (wavefront path; zero on the per-pixel path) */
     uint64_t shadow_rays;
     uint64_t shadow_inner_nodes;

@@ -38,7 +38,7 @@ class _Image(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("inner_nodes", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint32), ("batches", C.c_uint32),
                 ("shadow_rays", C.c_uint64), ("shadow_inner_nodes", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
                 ("path_ms", C.c_float), ("shadow_ms", C.c_float)]
 

@@ -63,9 +63,10 @@ struct rt_ctx {
     // five HIP events per render launch since the last stats read: start, after the path
     // kernel, before and after the shadow kernel, end (the middle three only on the
     // wavefront path, first batch)
-    std::vector<hipEvent_t> evPool;
-    std::vector<uint8_t> evHasMarks;
-    size_t evUsed = 0;
+    // timing: two events around every render (evPool), four per pixel batch of the wavefront
+    // path (markPool: batch start, after the path kernel, before and after the shadow traversal)
+    std::vector<hipEvent_t> evPool, markPool;
+    size_t evUsed = 0, marksUsed = 0;
     DevScene scene {};
     bool haveScene = false;
     uint32_t numLevels = 1;
@@ -192,6 +193,8 @@ void rt_ctx_destroy(rt_ctx* ctx)
     for (void* p : ctx->wsPtr)
         if (p)
             (void)hipFree(p);
+    for (hipEvent_t e : ctx->markPool)
+        (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->evPool)
         (void)hipEventDestroy(e);
     delete ctx;
@@ -957,20 +960,18 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, collect ? sizeof(DevCounters) : offsetof(DevCounters, waveLog), stream));
     if (timeIt) {
-        if (ctx->evUsed + 5 > ctx->evPool.size()) {
-            if (ctx->evPool.size() >= 5 * 4096) { // unread launches pile up: fold them by waiting once
+        if (ctx->evUsed + 2 > ctx->evPool.size()) {
+            if (ctx->evPool.size() >= 2 * 4096) { // unread launches pile up: fold them by waiting once
                 HIP_TRY(ctx, hipStreamSynchronize(stream));
-                ctx->evUsed = 0;
+                ctx->evUsed = ctx->marksUsed = 0;
             } else {
-                for (int i = 0; i < 5; i++) {
+                for (int i = 0; i < 2; i++) {
                     hipEvent_t a;
                     HIP_TRY(ctx, hipEventCreate(&a));
                     ctx->evPool.push_back(a);
                 }
-                ctx->evHasMarks.push_back(0);
             }
         }
-        ctx->evHasMarks[ctx->evUsed / 5] = 0;
         HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed], stream));
     }
 
@@ -1096,9 +1097,15 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             const int pathBlocks = ctx->numCU * pathPerCU;
             const int shadowBlocks = ctx->numCU * shadowPerCU;
             hipEvent_t* marks = nullptr;
-            if (timeIt && begin == 0) {
-                marks = &ctx->evPool[ctx->evUsed + 1];
-                ctx->evHasMarks[ctx->evUsed / 5] = 1;
+            if (timeIt && ctx->marksUsed + 4 <= (1u << 18)) { // (beyond that many unread batches, only the frame is timed)
+                while (ctx->markPool.size() < ctx->marksUsed + 4) {
+                    hipEvent_t a;
+                    HIP_TRY(ctx, hipEventCreate(&a));
+                    ctx->markPool.push_back(a);
+                }
+                HIP_TRY(ctx, hipEventRecord(ctx->markPool[ctx->marksUsed], stream));
+                marks = &ctx->markPool[ctx->marksUsed + 1];
+                ctx->marksUsed += 4;
             }
             HIP_TRY(ctx, launchWavefront(dof, collect, transp, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
                               wb, ctx->dCounters, dOut, traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB),
@@ -1111,8 +1118,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             return rb;
     }
     if (timeIt) {
-        HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed + 4], stream));
-        ctx->evUsed += 5;
+        HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed + 1], stream));
+        ctx->evUsed += 2;
     }
     return RT_OK;
 }
@@ -1166,23 +1173,25 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
         stats->shadow_inner_nodes = c.sInner;
         stats->shadow_tri_tests = c.sTris;
         stats->kernel_ms = stats->path_ms = stats->shadow_ms = 0.0f;
-        stats->launches = 0;
+        stats->launches = stats->batches = 0;
         if (timed) {
-            for (size_t i = 0; i + 4 < ctx->evUsed; i += 5) {
+            for (size_t i = 0; i + 1 < ctx->evUsed; i += 2) {
                 float ms = 0.0f;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 4]));
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]));
                 stats->kernel_ms += ms;
                 stats->launches++;
-                if (ctx->evHasMarks[i / 5]) {
-                    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]));
-                    stats->path_ms += ms;
-                    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i + 2], ctx->evPool[i + 3]));
-                    stats->shadow_ms += ms;
-                }
+            }
+            for (size_t i = 0; i + 3 < ctx->marksUsed; i += 4) {
+                float ms = 0.0f;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->markPool[i], ctx->markPool[i + 1]));
+                stats->path_ms += ms;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->markPool[i + 2], ctx->markPool[i + 3]));
+                stats->shadow_ms += ms;
+                stats->batches++;
             }
         }
     }
-    ctx->evUsed = 0;
+    ctx->evUsed = ctx->marksUsed = 0;
     return RT_OK;
 }
 
