@@ -174,7 +174,7 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
     if (const char* s = getenv("RT_AMD_PER_PIXEL"))
         ctx->forcePerPixel = atoi(s);
     if (const char* s = getenv("RT_AMD_WORKSPACE_GB"))
-        ctx->workspaceCap = static_cast<size_t>(std::max(1, atoi(s))) << 30;
+        ctx->workspaceCap = static_cast<size_t>(std::max(1.0, atof(s) * 1024.0)) << 20; // fractions allowed, at least 1 MiB
     *out = ctx;
     return RT_OK;
 }
