@@ -80,6 +80,7 @@ struct rt_ctx {
     // lanes blocked before triangles are tested; lanes still holding a leaf when inner steps resume
     int parkA = 16, parkB = 32, parkAShadow = 16, parkBShadow = 32;
     int chunkPath = 128, chunkShadow = 512; // rays a wavefront takes from the queue at a time
+    int ownShare = 0;                       // sixteenths of a queue its waves split up by position (beyond the first batch)
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
     int forcePerPixel = 0; // 1 = always use the per-pixel kernel
@@ -163,6 +164,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->parkBShadow = atoi(s);
     if (const char* s = getenv("RT_AMD_CHUNK_PATH"))
         ctx->chunkPath = std::max(64, atoi(s));
+    if (const char* s = getenv("RT_AMD_OWN_SHARE"))
+        ctx->ownShare = std::min(16, std::max(0, atoi(s)));
     if (const char* s = getenv("RT_AMD_CHUNK_SHADOW"))
         ctx->chunkShadow = std::max(64, atoi(s));
     if (const char* s = getenv("RT_AMD_LOGIC_ROUNDS"))
@@ -1014,6 +1017,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         wp.mainStart = wp.pixDraws + (F.enableDepthOfField ? 2u * ft.camRays * F.numDepthOfFieldSamples : 0u);
         wp.chunk = ctx->chunkShadow;
         wp.chunkPath = ctx->chunkPath;
+        wp.ownShare = ctx->ownShare;
         if (wp.R == 0 || wp.R > 65535u)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
         const bool dof = F.enableDepthOfField != 0;
@@ -1085,7 +1089,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             wp.slotBegin = static_cast<uint32_t>(begin);
             wp.nSlots = static_cast<uint32_t>(std::min<uint64_t>(batchSlots, fr.nWork - begin));
             if (begin != 0) // queue heads and the node allocator start over; the ray counters keep adding up
-                HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctx->dCounters) + offsetof(DevCounters, next), 0, 16, stream));
+                HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctx->dCounters) + offsetof(DevCounters, next), 0,
+                    offsetof(DevCounters, loopIters) - offsetof(DevCounters, next), stream));
             // real pixels of the batch's tiles (edge tiles are padded to 8x8 slots)
             uint64_t validPixels = 0;
             for (uint64_t t = begin / 64; t < (begin + wp.nSlots) / 64; t++) {

@@ -163,11 +163,19 @@ struct DevFrame {
     int32_t packed; // 0: write Screen order, 1: write shard-packed tiles
 };
 
+// A counter that many waves update at once, alone in its 128-B line: atomics on one line are
+// served one after the other, whatever their addresses within it.
+struct alignas(128) HotCounter {
+    uint32_t v;
+    uint32_t pad[31];
+};
+
 struct DevCounters {
     unsigned long long rays, inner, tris;       // accumulated over the frame, all kernels
     unsigned long long sRays, sInner, sTris;    // the shadow kernel's share of them
-    // work-queue heads and the node allocator; cleared before every batch
-    uint32_t next, nextShadow, nodes, camQueued;
+    // work-queue heads, the node allocator, the number of queued camera rays, and the flags the first
+    // wave to find a queue empty raises for the others ([0] path, [1] shadow); cleared before every batch
+    HotCounter next, nextShadow, nodes, camQueued, dry[2];
     // counting launches only: iterations of the traversal loop summed over all 64 lanes of
     // every wave (divide by 64 for wave iterations), [0] inner [1] leaf [2] calls of run()
     unsigned long long loopIters[2][3]; // [0] path kernel, [1] shadow kernel

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
                     }
                     uint32_t base = 0;
                     if (lane == (uint32_t)__builtin_ctzll(wm))
-                        base = atomicAdd(&ctr->next, 64u);
+                        base = atomicAdd(&ctr->next.v, 64u);
                     base = __shfl(base, __builtin_ctzll(wm)) + nWaves * 64u;
                     if (base >= fr.nWork) {
                         exhausted = true;

@@ -1,10 +1,10 @@
 // rt_wavefront.hip -- the queue-based (wavefront) form of renderImage for
-// gfx950, used whenever neither transparency nor glossy reflection is on.
+// gfx950, used unless glossy reflection is on.
 //
 // The reference consumes ONE Sampler stream per pixel, depth first
 // (src/render.cpp:34-39).  Which rays a pixel's ray tree contains, though, does
 // not depend on the draws: camera rays take their draws from fixed positions at
-// the head of the stream, reflection directions are pure geometry, and only
+// the head of the stream, reflection and pass-through directions are pure geometry, and only
 // the light samples (src/light.cpp:205-253) draw from the rest, a fixed number
 // D per shaded hit.  So the position of every draw is known once the hits of
 // the pixel are counted: hit number k of the pixel (camera rays in order, each
@@ -46,12 +46,43 @@ __device__ __forceinline__ uint32_t lcgSkip(uint32_t state, uint32_t k)
 }
 
 // Wave-level queue: every lane whose `want` is set receives the next work item
-// in `item`, or -1 when the queue is empty.  cursor/cend are wave-uniform.
+// in `item`, or is marked dead when the queue is empty.  All members are wave-uniform.
+// One address takes fewer than a hundred atomics per microsecond, so a round of several
+// thousand waves asking at once costs more than a small frame's whole traversal.  Hence:
+// the head of the queue is each wave's own by position (wave w owns [w*own, (w+1)*own), no
+// atomic), the rest is handed out in batches by the atomic counter, and the first wave to find
+// it empty raises a flag (in another cache line) that the others read instead of asking the
+// counter themselves.  `own` is one batch by default: a larger positional share was measured
+// and lost more to uneven finishing times (rays differ widely in cost) than it saved in atomics.
 struct WaveQueue {
     uint32_t cursor = 0, cend = 0;
+    uint32_t shared = 0; // where the atomically handed-out part begins
+    uint32_t chunk = 0;  // its batch size
     bool exhausted = false;
 
-    __device__ __forceinline__ void fetch(bool& want, uint32_t& item, bool& dead, uint32_t* counter, uint32_t total, uint32_t chunk,
+    // sixteenths: the part of the queue split up by position; configured/least: bounds of the batch size
+    __device__ __forceinline__ void start(uint32_t total, uint32_t sixteenths, uint32_t configured, uint32_t least)
+    {
+        const uint32_t wavesPerBlock = blockDim.x / 64u;
+        const uint32_t nWaves = gridDim.x * wavesPerBlock;
+        const uint32_t wave = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6);
+        uint32_t own = (uint32_t)(((unsigned long long)total * sixteenths / 16u) / nWaves);
+        if (own < least)
+            own = least;
+        shared = nWaves * own; // below total + 2^26 with the batch sizes in use
+        // a few batches per wave, so that the waves still finish close together
+        const uint32_t rest = shared < total ? total - shared : 0u;
+        const uint32_t share = rest / (nWaves * 2u);
+        chunk = share >= configured ? configured : (share < least ? least : share);
+        cursor = wave * own;
+        cend = (cursor + own < total) ? cursor + own : total;
+        if (cursor >= total) {
+            cursor = cend = 0;
+            exhausted = true;
+        }
+    }
+
+    __device__ __forceinline__ void fetch(bool& want, uint32_t& item, bool& dead, HotCounter* counter, HotCounter* dry, uint32_t total,
         uint32_t lane)
     {
         for (;;) {
@@ -59,6 +90,8 @@ struct WaveQueue {
             if (wm == 0ull)
                 return;
             if (cursor == cend) {
+                if (!exhausted && (shared >= total || __hip_atomic_load(&dry->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
+                    exhausted = true;
                 if (exhausted) {
                     if (want) {
                         dead = true;
@@ -69,9 +102,11 @@ struct WaveQueue {
                 uint32_t base = 0;
                 const int leader = __builtin_ctzll(wm);
                 if (lane == (uint32_t)leader)
-                    base = atomicAdd(counter, chunk);
-                base = __shfl(base, leader);
+                    base = atomicAdd(&counter->v, chunk);
+                base = shared + __shfl(base, leader);
                 if (base >= total) {
+                    if (lane == (uint32_t)leader)
+                        __hip_atomic_store(&dry->v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     exhausted = true;
                     continue;
                 }
@@ -89,15 +124,6 @@ struct WaveQueue {
         }
     }
 };
-
-// Rays a wave takes from its queue per atomic: the configured batch when there is plenty of
-// work, less when the whole queue is only a few batches per wave (a shard of a frame on one of
-// many GPUs), so that the waves still finish close together; never below `least`.
-__device__ __forceinline__ uint32_t queueChunk(uint32_t total, uint32_t configured, uint32_t least)
-{
-    const uint32_t share = total / (gridDim.x * (blockDim.x / 64u) * 4u);
-    return share >= configured ? configured : (share < least ? least : share);
-}
 
 __device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
 {
@@ -157,7 +183,7 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t n = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
-        blockBase = n ? atomicAdd(&ctr->camQueued, n) : 0u;
+        blockBase = n ? atomicAdd(&ctr->camQueued.v, n) : 0u;
     }
     __syncthreads();
     if (queue) {
@@ -184,8 +210,12 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
     extern __shared__ uint32_t stackMem[];
     const Tracer<STATS> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = ctr->camQueued;
-    const uint32_t chunk = queueChunk(total, wp.chunkPath, 32u);
+    const uint32_t total = ctr->camQueued.v;
+    // node slots a wave reserves per atomic: about what its share of the rays will fill, so that a small
+    // frame does not leave most of the pool's touched part empty (every slot is a work item further on)
+    uint32_t nodeBlock = kNodeBlock;
+    while (nodeBlock > 64u && nodeBlock * (gridDim.x * (blockDim.x / 64u)) > 2u * total)
+        nodeBlock >>= 1;
 
     RayState r;
     r.active = false;
@@ -213,12 +243,13 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
     bool viaPass = false; // the ray in flight is the pass-through child of `prev` (else its mirror child)
     bool have = false, dead = false;
     WaveQueue q;
+    q.start(total, wp.ownShare, wp.chunkPath, 32u);
 
     for (;;) {
         // ---- lanes without a path take the next queued camera ray
         for (int round = 0; round < 2; round++) {
             bool want = !have && !dead;
-            q.fetch(want, item, dead, &ctr->next, total, chunk, lane);
+            q.fetch(want, item, dead, &ctr->next, &ctr->dry[0], total, lane);
             if (!have && !dead && !want) {
                 const float4 c0 = wb.camRays[2u * (size_t)item + 0], c1 = wb.camRays[2u * (size_t)item + 1];
                 path = __float_as_uint(c0.w);
@@ -259,7 +290,7 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
                     }
                 } else {
                     const HitCtx h = shadeHit(sc, ft, r);
-                    // One node per shaded hit.  Every wave owns a block of kNodeBlock consecutive slots of
+                    // One node per shaded hit.  Every wave owns a block of nodeBlock (>= 64) consecutive slots of
                     // the pool and hands them out itself; only a new block costs an atomic (one address
                     // takes well under a hundred of them per microsecond, far fewer than there are hits).
                     const unsigned long long am = __ballot(true);
@@ -271,14 +302,14 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
                     if (n > rem) {
                         const int leader = __builtin_ctzll(am);
                         if (lane == (uint32_t)leader)
-                            fresh = atomicAdd(&ctr->nodes, kNodeBlock);
+                            fresh = atomicAdd(&ctr->nodes.v, nodeBlock);
                         fresh = __shfl(fresh, leader);
                     }
                     const uint32_t idx = rank < rem ? nodeCur + rank : fresh + (rank - rem);
                     if (rank == 0) {
                         nodeBlk[0] = n > rem ? fresh + (n - rem) : nodeCur + n;
                         if (n > rem)
-                            nodeBlk[1] = fresh + kNodeBlock;
+                            nodeBlk[1] = fresh + nodeBlock;
                     }
                     if (idx < wb.maxNodes) { // always: the pool holds the worst case of the batch
                         made++;
@@ -370,11 +401,23 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
     const unsigned long long rs = waveSum(nrays), ni = waveSum(r.nInner), nt = waveSum(r.nTris);
     const unsigned long long ii = waveSum(r.itInner), il = waveSum(r.itLeaf), ir = waveSum(r.itRuns);
     const unsigned long long th[3] = { waveSum(r.topHits[0]), waveSum(r.topHits[1]), waveSum(r.topHits[2]) };
-    if (lane == 0) {
+    // ray counts: one pair of atomics per block that has something to add (thousands of idle
+    // waves adding zero to one address would take longer than a small frame's traversal)
+    __shared__ unsigned long long raySums[4][2];
+    if (lane == 0)
+        raySums[threadIdx.x >> 6][0] = rs + srays, raySums[threadIdx.x >> 6][1] = srays;
+    __syncthreads();
+    if (threadIdx.x == 0) {
         // reflection rays counted here; every camera ray of a real pixel is one intersect call, traced or not
-        atomicAdd(&ctr->rays, rs + srays + ((blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)wp.validPaths : 0ull));
-        if (srays)
-            atomicAdd(&ctr->sRays, srays);
+        const unsigned long long all = raySums[0][0] + raySums[1][0] + raySums[2][0] + raySums[3][0]
+            + (blockIdx.x == 0 ? (unsigned long long)wp.validPaths : 0ull);
+        const unsigned long long shadow = raySums[0][1] + raySums[1][1] + raySums[2][1] + raySums[3][1];
+        if (all)
+            atomicAdd(&ctr->rays, all);
+        if (shadow)
+            atomicAdd(&ctr->sRays, shadow);
+    }
+    if (lane == 0) {
         if (STATS) {
             atomicAdd(&ctr->inner, ni);
             atomicAdd(&ctr->tris, nt);
@@ -448,7 +491,7 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
     typedef __attribute__((address_space(4))) const uint32_t* ConstWords;
     const ConstWords lights = (ConstWords)(uintptr_t)lightsGlobal;
     constexpr uint32_t kLightWords = sizeof(rt_light) / 4;
-    const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
+    const uint32_t nNodes = ctr->nodes.v < wb.maxNodes ? ctr->nodes.v : wb.maxNodes;
     const uint32_t total = nNodes * wp.slots; // host guarantees maxNodes * slots < 2^32
     for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
         const uint32_t item = base + threadIdx.x;
@@ -545,9 +588,8 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     extern __shared__ uint32_t stackMem[];
     const Tracer<STATS> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nNodesAll = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
+    const uint32_t nNodesAll = ctr->nodes.v < wb.maxNodes ? ctr->nodes.v : wb.maxNodes;
     const uint32_t total = ft.shadows ? nNodesAll * wp.slots : 0u; // shadows off: no ray at all (src/light.cpp:270-272)
-    const uint32_t chunk = queueChunk(total, wp.chunk, 64u);
 
     RayState r;
     r.active = false;
@@ -563,12 +605,13 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
     uint32_t item = 0, extra = 0;
     bool have = false, dead = false;
     WaveQueue q;
+    q.start(total, wp.ownShare, wp.chunk, 64u);
     f3 curKd = mk3(0.0f); // TRANSP: kd of the last surface the light went through, and the product of
     float tprod = 1.0f;   // the transparencies on the way
 
     for (;;) {
         bool want = !have && !dead;
-        q.fetch(want, item, dead, &ctr->nextShadow, total, chunk, lane);
+        q.fetch(want, item, dead, &ctr->nextShadow, &ctr->dry[1], total, lane);
         if (!have && !dead && !want) {
             const float4* sr = wb.srays + 3u * (size_t)item;
             const float4 a = sr[0], b = sr[1];
@@ -666,7 +709,7 @@ __global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, cons
 __global__ __launch_bounds__(256) void shadowShadeKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     const DevCounters* __restrict__ ctr)
 {
-    const uint32_t nNodes = ctr->nodes < wb.maxNodes ? ctr->nodes : wb.maxNodes;
+    const uint32_t nNodes = ctr->nodes.v < wb.maxNodes ? ctr->nodes.v : wb.maxNodes;
     const uint32_t total = nNodes * wp.slots;
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
         f3 c = { 0.0f, 0.0f, 0.0f };

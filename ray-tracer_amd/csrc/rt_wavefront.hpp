@@ -49,8 +49,9 @@ struct WfParams {
     uint32_t drawsPerHit;
     uint32_t pixDraws;   // draws of the pixel-sample stretch
     uint32_t mainStart;  // position of the first light-sample draw
-    uint32_t chunk;      // shadow rays per queue fetch
-    uint32_t chunkPath;  // camera rays per queue fetch
+    uint32_t chunk;      // shadow rays per queue fetch, at most
+    uint32_t chunkPath;  // camera rays per queue fetch, at most
+    uint32_t ownShare;   // sixteenths of a queue that its waves split up by position instead of fetching
     uint32_t validPaths; // camera rays of the batch's real (non-padding) pixels
 };
 
