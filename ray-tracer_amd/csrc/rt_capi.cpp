@@ -957,7 +957,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     fr.nWork = static_cast<uint32_t>(shardTiles(width, height, shard, nShard) * 64);
     fr.packed = (nShard == 1) ? 0 : 1;
 
-    const int blockThreads = 256;
+    const int blockThreads = kBlockThreads;
+    const int maxPerCU = 32 / kBlockWaves; // a compute unit holds 32 wavefronts
     const uint32_t stackEntries = std::max<uint32_t>(ctx->numLevels, 2) + 1; // one more for the bottom marker
     const size_t lds = static_cast<size_t>(stackEntries) * blockThreads * 4;
 
@@ -993,10 +994,10 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         int perCU = ctx->blocksPerCU;
         if (perCU <= 0) {
             HIP_TRY(ctx, renderOccupancy(variant, blockThreads, lds, &perCU));
-            perCU = std::max(1, std::min(perCU, 8));
+            perCU = std::max(1, std::min(perCU, maxPerCU));
         }
         const uint32_t wavesNeeded = fr.nWork / 64;
-        int blocks = std::min<int64_t>(static_cast<int64_t>(ctx->numCU) * perCU, (wavesNeeded + 3) / 4);
+        int blocks = std::min<int64_t>(static_cast<int64_t>(ctx->numCU) * perCU, (wavesNeeded + kBlockWaves - 1) / kBlockWaves);
         blocks = std::max(blocks, 1);
         HIP_TRY(ctx, launchRender(variant, blocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, ctx->dCounters, dOut,
                           traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB), ctx->logicRounds));
@@ -1026,7 +1027,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         HIP_TRY(ctx, wavefrontOccupancy(collect, transp, blockThreads, lds, &pathPerCU, &shadowPerCU));
         if (pathPerCU < 1 || shadowPerCU < 1)
             return fail(ctx, RT_ERR_DEVICE, "render: the traversing kernels do not fit a compute unit (%zu B of LDS)", lds);
-        pathPerCU = std::min(pathPerCU, 8), shadowPerCU = std::min(shadowPerCU, 8);
+        pathPerCU = std::min(pathPerCU, maxPerCU), shadowPerCU = std::min(shadowPerCU, maxPerCU);
         if (ctx->blocksPerCU > 0) { // experiments: fewer blocks than fit
             pathPerCU = std::min(pathPerCU, ctx->blocksPerCU);
             shadowPerCU = std::min(shadowPerCU, ctx->blocksPerCU);
@@ -1398,7 +1399,7 @@ int rt_intersect_batch(rt_ctx* ctx, rt_ray* rays, uint32_t n, rt_hit* hits)
         e = hipMemcpy(dRays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const DevFeat ft = makeFeat(ctx->features);
-        const int blockThreads = 256;
+        const int blockThreads = kBlockThreads;
         const size_t lds = static_cast<size_t>(std::max<uint32_t>(ctx->numLevels, 2) + 1) * blockThreads * 4; // + the bottom marker
         e = launchIntersect(blockThreads, lds, nullptr, ctx->scene, ft, dRays, dHits, n);
     }

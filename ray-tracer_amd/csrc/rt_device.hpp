@@ -163,6 +163,14 @@ struct DevFrame {
     int32_t packed; // 0: write Screen order, 1: write shard-packed tiles
 };
 
+// Threads per block of every kernel that traverses (their LDS stacks are laid out for it).
+#ifndef RT_BLOCK_THREADS
+#define RT_BLOCK_THREADS 256
+#endif
+constexpr uint32_t kBlockThreads = RT_BLOCK_THREADS;
+constexpr uint32_t kBlockWaves = kBlockThreads / 64u;
+static_assert(kBlockThreads % 64u == 0 && kBlockThreads >= 64u && kBlockThreads <= 256u, "whole wavefronts, at most four");
+
 // A counter that many waves update at once, alone in its 128-B line: atomics on one line are
 // served one after the other, whatever their addresses within it.
 struct alignas(128) HotCounter {

@@ -387,7 +387,7 @@ struct Shader {
 #endif
 
 template <int V>
-__global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene sc, const DevCamera cam, const DevFeat ft,
+__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void renderKernel(const DevScene sc, const DevCamera cam, const DevFeat ft,
     const DevFrame fr, DevCounters* __restrict__ ctr, float* __restrict__ out, int minActive, int logicRounds)
 {
     extern __shared__ uint32_t stackMem[];
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void renderKernel(const DevScene
 // ----------------------------------------------------------------------------
 // BVHInterface::intersect for a batch of rays: one lane per ray, same traversal.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void intersectKernel(const DevScene sc, const DevFeat ft, rt_ray* __restrict__ rays,
+__global__ __launch_bounds__(kBlockThreads) void intersectKernel(const DevScene sc, const DevFeat ft, rt_ray* __restrict__ rays,
     rt_hit* __restrict__ hits, uint32_t n)
 {
     extern __shared__ uint32_t stackMem[];

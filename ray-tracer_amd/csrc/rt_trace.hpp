@@ -13,8 +13,6 @@
 
 namespace rt {
 
-constexpr uint32_t kBlockThreads = 256;
-
 enum RayKind : int { K_RADIANCE = 0, K_SHADOW_ANY = 1, K_SHADOW_CLOSEST = 2 };
 
 constexpr int kHitNone = -1;
@@ -58,7 +56,7 @@ struct Tracer {
     const DevScene& sc;
     int accel;
     LdsWords stk; // this lane's column of the LDS stack
-    static constexpr uint32_t stride = kBlockThreads; // every traversing kernel runs 256-thread blocks
+    static constexpr uint32_t stride = kBlockThreads; // every traversing kernel runs blocks of this size
 
     // The bottom entry of every stack holds kRefNone (begin()), so a pop needs no
     // emptiness check: the last pop of a traversal returns "no node".

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
 #define RT_PATH_ATTR
 #endif
 template <bool STATS, bool TRANSP>
-__global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+__global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
@@ -229,14 +229,14 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
     const long long tKernel = STATS ? clock64() : 0;
     const long long tWall = STATS ? wall_clock64() : 0; // 100 MHz, the same on every XCD (the shader clock is not)
     uint32_t path = 0, item = 0, nrays = 0, made = 0;
-    __shared__ uint32_t nodeBlkAll[4][2]; // per wave: next free slot and end of its block of node slots
+    __shared__ uint32_t nodeBlkAll[kBlockWaves][2]; // per wave: next free slot and end of its block of node slots
     volatile __attribute__((address_space(3))) uint32_t* nodeBlk = (volatile __attribute__((address_space(3))) uint32_t*)nodeBlkAll[threadIdx.x >> 6];
     if (lane == 0)
         nodeBlk[0] = nodeBlk[1] = 0u;
     // With transparency a hit can have two children.  The mirror child is followed first, like
     // renderRay does; the hit itself waits on this per-lane stack (entry-major in LDS) for its
     // pass-through ray, which is rebuilt from the hit's record when its turn comes.
-    __shared__ uint32_t waitingAll[TRANSP ? (kMaxDepth + 1) * 256 : 1];
+    __shared__ uint32_t waitingAll[TRANSP ? (kMaxDepth + 1) * kBlockThreads : 1];
     uint32_t* waiting = waitingAll + (TRANSP ? threadIdx.x : 0u);
     int nWaiting = 0;
     int depth = 0, prev = -1, count = 0;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
                             const bool wantPass = TRANSP && ft.transparency && h.tr != 1.0f;
                             if (wantRefl) {
                                 if (wantPass)
-                                    waiting[256 * nWaiting++] = idx;
+                                    waiting[kBlockThreads * nWaiting++] = idx;
                                 f3 o, d;
                                 reflectionRay(h.P, r.d, h.N, o, d);
                                 tracer.launch(r, o, d, kFltMax, K_RADIANCE);
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
                 if (!childLaunched) {
                     // this branch of the ray tree is done: the deepest hit still waiting gets its pass-through ray
                     if (TRANSP && nWaiting > 0) {
-                        const uint32_t w = waiting[256 * --nWaiting];
+                        const uint32_t w = waiting[kBlockThreads * --nWaiting];
                         const float4* a = wb.nodeA + 4u * (size_t)w;
                         const float4 a0 = a[0], a1 = a[1], a2 = a[2];
                         const f3 P = { a0.x, a0.y, a0.z }, rd = { a1.z, a1.w, a2.x };
@@ -403,15 +403,15 @@ __global__ __launch_bounds__(256) RT_PATH_ATTR void pathKernel(const DevScene sc
     const unsigned long long th[3] = { waveSum(r.topHits[0]), waveSum(r.topHits[1]), waveSum(r.topHits[2]) };
     // ray counts: one pair of atomics per block that has something to add (thousands of idle
     // waves adding zero to one address would take longer than a small frame's traversal)
-    __shared__ unsigned long long raySums[4][2];
+    __shared__ unsigned long long raySums[kBlockWaves][2];
     if (lane == 0)
         raySums[threadIdx.x >> 6][0] = rs + srays, raySums[threadIdx.x >> 6][1] = srays;
     __syncthreads();
     if (threadIdx.x == 0) {
         // reflection rays counted here; every camera ray of a real pixel is one intersect call, traced or not
-        const unsigned long long all = raySums[0][0] + raySums[1][0] + raySums[2][0] + raySums[3][0]
-            + (blockIdx.x == 0 ? (unsigned long long)wp.validPaths : 0ull);
-        const unsigned long long shadow = raySums[0][1] + raySums[1][1] + raySums[2][1] + raySums[3][1];
+        unsigned long long all = blockIdx.x == 0 ? (unsigned long long)wp.validPaths : 0ull, shadow = 0ull;
+        for (uint32_t w = 0; w < kBlockWaves; w++)
+            all += raySums[w][0], shadow += raySums[w][1];
         if (all)
             atomicAdd(&ctr->rays, all);
         if (shadow)
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
 // test: the closest hit along the ray; a hit short of the shaded point on a material that is
 // not opaque tints the light and the ray goes on from there.
 template <bool STATS, bool TRANSP>
-__global__ __launch_bounds__(256) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+__global__ __launch_bounds__(kBlockThreads) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
