@@ -83,6 +83,7 @@ struct rt_ctx {
     int ownShare = 0;                       // sixteenths of a queue its waves split up by position (beyond the first batch)
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
+    int pathBlocksPerCU = 0; // the same for the path kernel alone
     int forcePerPixel = 0; // 1 = always use the per-pixel kernel
     int treeMode = 1;      // 0 = traverse the caller's inner nodes as they are, 1 = own SAH hierarchy over the caller's leaves
     size_t workspaceCap = 64ull << 30; // bytes the wavefront path may hold
@@ -172,6 +173,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->logicRounds = std::max(1, atoi(s));
     if (const char* s = getenv("RT_AMD_BLOCKS_PER_CU"))
         ctx->blocksPerCU = atoi(s);
+    if (const char* s = getenv("RT_AMD_PATH_BLOCKS_PER_CU"))
+        ctx->pathBlocksPerCU = atoi(s);
     if (const char* s = getenv("RT_AMD_TREE"))
         ctx->treeMode = atoi(s);
     if (const char* s = getenv("RT_AMD_PER_PIXEL"))
@@ -1032,6 +1035,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             pathPerCU = std::min(pathPerCU, ctx->blocksPerCU);
             shadowPerCU = std::min(shadowPerCU, ctx->blocksPerCU);
         }
+        if (ctx->pathBlocksPerCU > 0)
+            pathPerCU = std::min(pathPerCU, ctx->pathBlocksPerCU);
         // every wavefront of the path kernel may leave part of its last block of node slots unused
         const uint64_t nodeSlack = static_cast<uint64_t>(ctx->numCU) * pathPerCU * (blockThreads / 64) * kNodeBlock;
         // Hits one camera ray can make.  A hit below the depth cap has a mirror child if its material
