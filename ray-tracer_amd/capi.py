@@ -129,11 +129,12 @@ class Context:
             raise RtError(rc, lib().rt_last_error(self.handle).decode())
 
     # -- scene ----------------------------------------------------------
-    def upload_scene(self, scene, nodes=None, prims=None):
-        """Build the BVH over `scene` (unless nodes/prims are given), upload it
-        with materials / textures / spheres, and set the scene's lights."""
+    def upload_scene(self, scene, nodes=None, prims=None, sah_binning=False):
+        """Build the BVH over `scene` (unless nodes/prims are given; `sah_binning` is
+        Features::extra.enableBvhSahBinning), upload it with materials / textures /
+        spheres, and set the scene's lights."""
         if nodes is None:
-            nodes, prims, self.num_levels, self.num_leaves = bvh_build(scene.primitives())
+            nodes, prims, self.num_levels, self.num_leaves = bvh_build(scene.primitives(), sah_binning)
         self.nodes = np.ascontiguousarray(nodes, dtype=sio.NODE)
         self.prims = np.ascontiguousarray(prims, dtype=sio.PRIMITIVE)
         mats = scene.materials()
