@@ -15,6 +15,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "rt_device.hpp"
@@ -65,6 +66,7 @@ struct rt_ctx {
     // wavefront path, first batch)
     // timing: two events around every render (evPool), four per pixel batch of the wavefront
     // path (markPool: batch start, after the path kernel, before and after the shadow traversal)
+    std::unique_ptr<DevCounters> hostCounters; // where readStats copies the device counters to
     std::vector<hipEvent_t> evPool, markPool;
     size_t evUsed = 0, marksUsed = 0;
     DevScene scene {};
@@ -85,7 +87,9 @@ struct rt_ctx {
     int blocksPerCU = 0; // 0 = ask the occupancy API
     int pathBlocksPerCU = 0; // the same for the path kernel alone
     int forcePerPixel = 0; // 1 = always use the per-pixel kernel
-    int treeMode = 1;      // 0 = traverse the caller's inner nodes as they are, 1 = own SAH hierarchy over the caller's leaves
+    // 0 = traverse the caller's inner nodes as they are; 1 = own SAH hierarchy over the caller's leaves;
+    // 2 = own SAH hierarchy over the caller's primitives, each a leaf of its own under its own box
+    int treeMode = 2;
     size_t workspaceCap = 64ull << 30; // bytes the wavefront path may hold
     // wavefront workspace (grow-only)
     void* wsPtr[10] = {};
@@ -510,12 +514,16 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
     uint32_t rootRef = 0;
     bool ownTree = false;
     if (ctx->treeMode != 0 && !innerOrder.empty()) {
-        // Traversal tree of the library's own: the caller's LEAVES (their primitive ranges,
-        // boxes and order are kept as they are) under a new inner hierarchy chosen by the
-        // surface-area heuristic.  Which primitive a ray hits, its t and the order of the
-        // tests inside a leaf do not depend on the inner hierarchy, only the number of
-        // nodes a ray has to visit does (the median split of src/bvh.cpp:208-223 leaves
-        // heavily overlapping boxes).
+        // Traversal tree of the library's own, chosen by the surface-area heuristic: over the
+        // caller's primitives, every one a leaf under its own tight box (mode 2), or over the
+        // caller's leaves with their primitive ranges and boxes as they are (mode 1).  Which
+        // primitive a ray hits and its t do not depend on the hierarchy; only the number of boxes
+        // and primitives a ray has to test does.  (Of two primitives hit at exactly the same t
+        // the reference keeps the one it tests later, and so does this traversal, but which one
+        // that is can differ; such pairs share an edge, and on it material and interpolated
+        // attributes agree.)  The median
+        // split of src/bvh.cpp:208-223 leaves heavily overlapping boxes, and a leaf of four
+        // primitives makes a ray that grazes its box test all four.
         struct Leaf {
             float lo[3], hi[3], c[3];
             uint32_t ref, count;
@@ -531,6 +539,22 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
             }
             l.count = nodes[i].data[1];
             l.ref = kLeafFlag | (nodes[i].data[1] << 27) | (nodes[i].data[0] & ~RT_LEAF_BIT);
+            if (ctx->treeMode == 2) { // every primitive a leaf of its own, under its own box
+                const uint32_t first = nodes[i].data[0] & ~RT_LEAF_BIT;
+                for (uint32_t k = 0; k < nodes[i].data[1]; k++) {
+                    const rt_primitive& q = prims[first + k];
+                    Leaf t;
+                    for (int a = 0; a < 3; a++) {
+                        t.lo[a] = std::min(q.v0.position[a], std::min(q.v1.position[a], q.v2.position[a]));
+                        t.hi[a] = std::max(q.v0.position[a], std::max(q.v1.position[a], q.v2.position[a]));
+                        t.c[a] = 0.5f * (t.lo[a] + t.hi[a]);
+                    }
+                    t.count = 1;
+                    t.ref = kLeafFlag | (1u << 27) | (first + k);
+                    leaves.push_back(t);
+                }
+                continue;
+            }
             leaves.push_back(l);
         }
         struct Build {
@@ -777,6 +801,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
     std::memcpy(s.gridMin, gridMin, 12);
     std::memcpy(s.gridCell, gridCell, 12);
     s.nPrims = n_prims;
+    s.tieByIndex = (ownTree && ctx->treeMode == 2) ? 1 : 0;
     s.nMeshes = static_cast<int32_t>(n_meshes);
     s.nSpheres = static_cast<int32_t>(n_spheres);
     s.nTex = static_cast<int32_t>(n_images);
@@ -1137,7 +1162,9 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
 
 static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
 {
-    static DevCounters c; // large (per-wave log); calls on one context are not concurrent
+    if (!ctx->hostCounters) // large (per-wave log), so not on the stack; one per context
+        ctx->hostCounters.reset(new DevCounters());
+    DevCounters& c = *ctx->hostCounters;
     const bool debug = getenv("RT_AMD_DEBUG_COUNTERS") != nullptr;
     HIP_TRY(ctx, hipMemcpy(&c, ctx->dCounters, debug ? sizeof c : offsetof(DevCounters, waveLog), hipMemcpyDeviceToHost));
     if (getenv("RT_AMD_DEBUG_COUNTERS") && (c.loopIters[0][2] | c.loopIters[1][2])) {

@@ -133,6 +133,7 @@ struct DevScene {
     uint32_t nPrims;
     int32_t nMeshes, nSpheres, nLights, nTex;
     int32_t env[6];
+    int32_t tieByIndex; // equal-t hits: the higher primitive index wins, whatever the order of the tests
 };
 
 struct DevCamera {

@@ -8,7 +8,7 @@
 #include "rt_device.hpp"
 
 #ifndef RT_INNER_STEPS
-#define RT_INNER_STEPS 3 // sibling pairs a lane may visit between two votes of the traversal loop
+#define RT_INNER_STEPS 4 // sibling pairs a lane may visit between two votes of the traversal loop
 #endif
 
 namespace rt {
@@ -283,7 +283,11 @@ struct Tracer {
         float t;
         if (STATS)
             r.nTris++;
-        if (triangleTestLazy(sc.tris + r.li, r.o, r.d, r.tmax, t)) {
+        // Of two primitives hit at exactly the same t the reference keeps the one it tests later
+        // (t <= ray.t, src/bvh.cpp:272-279): inside a leaf that is the one with the higher index.
+        // A hierarchy of the library's own visits them in another order, so it decides by the index.
+        if (triangleTestLazy(sc.tris + r.li, r.o, r.d, r.tmax, t)
+            && !(sc.tieByIndex && t == r.tmax && r.hitPrim >= 0 && (int)(r.li / 6u) < r.hitPrim)) {
             r.tmax = t;
             r.hitPrim = (int)(r.li / 6u);
             // Binary visibility only asks whether the closest hit lies more

@@ -429,25 +429,28 @@ def _ctx_with_env(**env):  # (defined below the tests that use it; resolved at c
 
 def test_full_size_frame_properties():
     """BASELINE config 4 at its full size (dragon stand-in, 1920x1080, 16 spp, area light,
-    mirror depth 4), too large for the CPU oracle inside a test: the three independent
-    device paths must agree bit for bit -- wavefront kernels over the library's own
-    hierarchy, wavefront kernels over the caller's inner nodes, and the per-pixel kernel
-    that walks every pixel in the reference's depth-first order -- and count the same rays."""
+    mirror depth 4), too large for the CPU oracle inside a test: the independent device paths
+    must agree bit for bit -- wavefront kernels over the library's own hierarchy of single
+    primitives, over its hierarchy of the caller's leaves, over the caller's inner nodes, and
+    the per-pixel kernel that walks every pixel in the reference's depth-first order -- and
+    count the same rays."""
     import bench
     scn, f, w, h, _ = bench.build_workload("dragon")
     cam = sio.default_camera(w, h)
     results = []
-    for env in (dict(RT_AMD_TREE=1, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=0, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=1, RT_AMD_PER_PIXEL=1)):
+    for env in (dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=1, RT_AMD_PER_PIXEL=0),
+                dict(RT_AMD_TREE=0, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=1)):
         c = _ctx_with_env(**env)
         c.upload_scene(scn)
         c.set_features(f)
         img, st = c.render(cam, w, h)
         results.append((img, st["rays"]))
         c.close()
-    (a, ra), (b, rb), (p, rp) = results
-    assert ra == rb == rp and ra > 60_000_000
-    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    assert np.array_equal(a.view(np.uint32), p.view(np.uint32))
+    a, ra = results[0]
+    assert ra > 60_000_000
+    for img, rays in results[1:]:
+        assert rays == ra
+        assert np.array_equal(a.view(np.uint32), img.view(np.uint32))
     assert np.isfinite(a).all() and float(a.max()) <= 1.0 + 1e-6 and float(a.sum()) > 100.0
     # a 1/16-size crop of the same view against the oracle would need another camera; the small
     # configurations above pin the oracle, this one pins the size

@@ -1,0 +1,41 @@
+"""The headline frame at its full size from the CPU oracle and from the device under each
+traversal tree: ray counts, image differences, and the pixels where the trees disagree."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch  # noqa: E402,F401
+import bench  # noqa: E402
+import orc  # noqa: E402
+
+capi = importlib.import_module("ray-tracer_amd.capi")
+sio = importlib.import_module("ray-tracer_amd.scene_io")
+scene, features, w, h, desc = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "dragon")
+cam = sio.default_camera(w, h)
+t0 = time.time()
+ref, st_o = orc.OracleScene(scene).render(features, cam, w, h)
+print(f"oracle: {st_o['rays']} rays in {time.time() - t0:.1f} s", flush=True)
+imgs = {}
+for tree in (2, 1, 0):
+    os.environ["RT_AMD_TREE"] = str(tree)
+    ctx = capi.Context(0)
+    ctx.upload_scene(scene)
+    ctx.set_features(features)
+    img, st = ctx.render(cam, w, h)
+    ctx.close()
+    imgs[tree] = img
+    d = np.abs(img.astype(np.float64) - ref.astype(np.float64))
+    bad = np.argwhere(d.max(axis=2) > 2e-5)
+    print(f"tree {tree}: {st['rays']} rays (oracle {st_o['rays']:+d}: {st['rays'] - st_o['rays']:+d}), max abs {d.max():.3g}, "
+          f"{len(bad)} pixels beyond 2e-5: {bad[:8].tolist()}", flush=True)
+for tree in (1, 0):
+    diff = np.argwhere((imgs[2].view(np.uint32) != imgs[tree].view(np.uint32)).any(axis=2))
+    print(f"tree 2 vs tree {tree}: {len(diff)} pixels differ: {diff[:8].tolist()}")
+    for y, x in diff[:4]:
+        print("   ", (int(y), int(x)), "tree 2", imgs[2][y, x], f"tree {tree}", imgs[tree][y, x], "oracle", ref[y, x])
