@@ -652,7 +652,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
         rootRef = bld.build(0, static_cast<uint32_t>(leaves.size()), 1);
         if (bld.maxDepth + 1 <= (uint32_t)kMaxStack) {
             ownTree = true;
-            maxLevel = bld.maxDepth + 1;
+            maxLevel = bld.maxDepth; // nodes on the longest path from the root to a leaf, as for the caller's tree
             // breadth-first order: the records every ray starts with sit next to each other
             if ((rootRef & kLeafFlag) == 0) {
                 const uint32_t nPairs = static_cast<uint32_t>(pairs.size() / 2);
@@ -987,7 +987,9 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
 
     const int blockThreads = kBlockThreads;
     const int maxPerCU = 32 / kBlockWaves; // a compute unit holds 32 wavefronts
-    const uint32_t stackEntries = std::max<uint32_t>(ctx->numLevels, 2) + 1; // one more for the bottom marker
+    // A ray's stack holds the bottom marker and at most one waiting sibling per inner node on its path:
+    // a tree whose longest root-to-leaf path has L nodes needs L entries.
+    const uint32_t stackEntries = std::max<uint32_t>(ctx->numLevels, 2);
     const size_t lds = static_cast<size_t>(stackEntries) * blockThreads * 4;
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, collect ? sizeof(DevCounters) : offsetof(DevCounters, waveLog), stream));
@@ -1432,7 +1434,7 @@ int rt_intersect_batch(rt_ctx* ctx, rt_ray* rays, uint32_t n, rt_hit* hits)
     if (e == hipSuccess) {
         const DevFeat ft = makeFeat(ctx->features);
         const int blockThreads = kBlockThreads;
-        const size_t lds = static_cast<size_t>(std::max<uint32_t>(ctx->numLevels, 2) + 1) * blockThreads * 4; // + the bottom marker
+        const size_t lds = static_cast<size_t>(std::max<uint32_t>(ctx->numLevels, 2)) * blockThreads * 4; // as in renderCommon
         e = launchIntersect(blockThreads, lds, nullptr, ctx->scene, ft, dRays, dHits, n);
     }
     if (e == hipSuccess)
