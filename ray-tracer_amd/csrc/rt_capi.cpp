@@ -889,6 +889,7 @@ static DevFeat makeFeat(const rt_features& f)
     d.dof = f.enableDepthOfField, d.envMap = f.enableEnvironmentMap, d.glossy = f.enableGlossyReflection;
     d.glossySamples = f.numGlossySamples, d.glossyExponent = f.glossyExponent;
     d.dofDistance = f.depthOfFieldDistance, d.dofDiameter = f.depthOfFieldCircleDiameter, d.dofSamples = f.numDepthOfFieldSamples;
+    d.divDof = makeFastDiv(std::max(1u, f.numDepthOfFieldSamples));
     d.maxDepth = f.maxRayDepth;
     // src/render.cpp:58-70, :118: ray count and draws of the pixel-sample stretch
     d.jitterN = static_cast<uint32_t>(std::round(std::sqrt(static_cast<float>(f.numPixelSamples))));
@@ -981,6 +982,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     DevFrame fr {};
     fr.width = width, fr.height = height;
     fr.tilesX = (width + kTile - 1) / kTile, fr.tilesY = (height + kTile - 1) / kTile;
+    fr.divTilesX = makeFastDiv(static_cast<uint32_t>(fr.tilesX));
     fr.shard = shard, fr.nShard = nShard;
     fr.nWork = static_cast<uint32_t>(shardTiles(width, height, shard, nShard) * 64);
     fr.packed = (nShard == 1) ? 0 : 1;
@@ -1043,6 +1045,9 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             }
         }
         wp.slots = slots;
+        wp.divSlots = makeFastDiv(std::max(1u, slots));
+        wp.divR = makeFastDiv(wp.R);
+        wp.divPerRound = makeFastDiv(std::min(wp.R, 256u));
         wp.drawsPerHit = drawsPerHit;
         wp.pixDraws = (F.numPixelSamples > 1 ? 2u : 0u) * ft.camRays;
         wp.mainStart = wp.pixDraws + (F.enableDepthOfField ? 2u * ft.camRays * F.numDepthOfFieldSamples : 0u);

@@ -7,6 +7,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include "rt_fastdiv.hpp"
 #include <stdint.h>
 
 #include "../../include/rt_amd.h"
@@ -150,6 +151,7 @@ struct DevFeat {
     uint32_t glossySamples;
     float glossyExponent, dofDistance, dofDiameter;
     uint32_t dofSamples;
+    FastDiv divDof; // by max(dofSamples, 1)
     int32_t maxDepth;
     // derived per frame
     uint32_t raysPerPixel, jitterN, camRays;
@@ -159,6 +161,7 @@ struct DevFeat {
 
 struct DevFrame {
     int32_t width, height, tilesX, tilesY;
+    FastDiv divTilesX;
     int32_t shard, nShard;
     uint32_t nWork; // local pixels = local tiles * 64
     int32_t packed; // 0: write Screen order, 1: write shard-packed tiles

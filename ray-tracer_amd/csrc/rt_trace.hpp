@@ -386,9 +386,10 @@ __device__ __forceinline__ void cameraRay(const DevCamera& cam, const DevFeat& f
     uint32_t rayI, uint32_t& sPix, uint32_t& sLens, f3& pof, f3& o, f3& d)
 {
     const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
-    const uint32_t c = rayI / dofN;
+    const bool lens = DOF && ft.dof;
+    const uint32_t c = lens ? fastDiv(rayI, ft.divDof) : rayI;
     f3 dir = { 0.0f, 0.0f, 0.0f };
-    if (!(DOF && ft.dof) || (rayI % dofN) == 0) {
+    if (!lens || rayI - c * dofN == 0) {
         float ndcX, ndcY;
         const float W = (float)fr.width, H = (float)fr.height;
         if (ft.spp > 1) {
@@ -441,7 +442,8 @@ __device__ __forceinline__ bool slotToPixel(const DevFrame& fr, uint32_t slot, i
 {
     const uint32_t tileLocal = slot >> 6, within = slot & 63u;
     const uint32_t tile = tileLocal * (uint32_t)fr.nShard + (uint32_t)fr.shard;
-    const int tx = (int)(tile % (uint32_t)fr.tilesX), ty = (int)(tile / (uint32_t)fr.tilesX);
+    const uint32_t row = fastDiv(tile, fr.divTilesX);
+    const int tx = (int)(tile - row * (uint32_t)fr.tilesX), ty = (int)row;
     px = tx * kTile + (int)(within & 7u);
     py = ty * kTile + (int)(within >> 3);
     return px < fr.width && py < fr.height;

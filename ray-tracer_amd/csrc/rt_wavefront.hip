@@ -152,15 +152,17 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
     bool queue = false, enters = false;
     f3 o = { 0.0f, 0.0f, 0.0f }, d = { 0.0f, 0.0f, 0.0f };
     if (path < total) {
-        const uint32_t slot = wp.slotBegin + path / wp.R, i = path % wp.R;
+        const uint32_t pixel = fastDiv(path, wp.divR);
+        const uint32_t slot = wp.slotBegin + pixel, i = path - pixel * wp.R;
         int px, py;
         if (slotToPixel(fr, slot, px, py)) { // padding pixels of partial edge tiles have no rays
             const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
             const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
-            uint32_t sPix = (ft.spp > 1) ? lcgSkip(seed, 2u * (i / dofN)) : seed;
+            const uint32_t sample = (DOF && ft.dof) ? fastDiv(i, ft.divDof) : i; // i / dofN
+            uint32_t sPix = (ft.spp > 1) ? lcgSkip(seed, 2u * sample) : seed;
             uint32_t sLens = (DOF && ft.dof) ? lcgSkip(seed, wp.pixDraws + 2u * i) : seed;
             f3 pof = { 0.0f, 0.0f, 0.0f };
-            cameraRay<DOF>(cam, ft, fr, px, py, i - (i % dofN), sPix, sLens, pof, o, d);
+            cameraRay<DOF>(cam, ft, fr, px, py, sample * dofN, sPix, sLens, pof, o, d);
             enters = ft.accel && tracer.entersScene(o, rcp3(d));
             // without the acceleration structure, or with spheres in the scene, every ray has work left
             queue = enters || !ft.accel || sc.nSpheres != 0;
@@ -491,6 +493,11 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
     typedef __attribute__((address_space(4))) const uint32_t* ConstWords;
     const ConstWords lights = (ConstWords)(uintptr_t)lightsGlobal;
     constexpr uint32_t kLightWords = sizeof(rt_light) / 4;
+    // With transparency the light that arrives is only known after the traversal (it is tinted on the
+    // way): the sample is shaded afterwards, by shadowShadeKernel.  Otherwise it is shaded here, as if
+    // it arrived, and the traversal clears the contribution of an occluded sample: one kernel and a
+    // third of the record less.
+    const bool late = ft.transparency != 0;
     const uint32_t nNodes = ctr->nodes.v < wb.maxNodes ? ctr->nodes.v : wb.maxNodes;
     const uint32_t total = nNodes * wp.slots; // host guarantees maxNodes * slots < 2^32
     for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
@@ -502,8 +509,8 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
         uint32_t node = 0, path = 0, ordinal = 0;
         bool live = false;
         if (item < total) {
-            node = item / wp.slots;
-            const uint32_t sl = item % wp.slots;
+            node = fastDiv(item, wp.divSlots);
+            const uint32_t sl = item - node * wp.slots;
             uint32_t first = 0, draws = 0;
             for (int k = 0; k < sc.nLights; k++) {
                 const int type = (int)lights[k * kLightWords]; // rt_light::type
@@ -518,10 +525,16 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
             path = po.x, ordinal = po.y;
             live = l >= 0 && path != kDeadNode;
             if (!live) { // a slot no hit was written to: no ray, no light
-                float4* sr = wb.srays + 3u * (size_t)item;
-                sr[0] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-                sr[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                wb.svis[item] = 0;
+                if (late) {
+                    float4* sr = wb.srays + 3u * (size_t)item;
+                    sr[0] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+                    sr[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    wb.svis[item] = 0;
+                } else {
+                    wb.srays[2u * (size_t)item] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+                    float* dst = wb.contrib + 3u * (size_t)item;
+                    dst[0] = dst[1] = dst[2] = 0.0f;
+                }
             }
         }
         // One pass per distinct light among the wave's lanes (one, unless a wave straddles
@@ -544,7 +557,7 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
                 const float4 a0 = wb.nodeA[4u * (size_t)node];
                 const f3 P = { a0.x, a0.y, a0.z };
                 int px, py;
-                slotToPixel(fr, wp.slotBegin + path / wp.R, px, py);
+                slotToPixel(fr, wp.slotBegin + fastDiv(path, wp.divR), px, py);
                 const uint32_t seed = (uint32_t)(fr.height * px + py);
                 const uint32_t hitOrdinal = wb.pathBase[path] + ordinal;
                 uint32_t s = lcgSkip(seed, wp.mainStart + wp.drawsPerHit * hitOrdinal + drawPrefix + slot * perSample);
@@ -568,11 +581,27 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
                 } else { // src/light.cpp:270-272: no ray; keep minus the direction to the light
                     d = -normalize(pos - P);
                 }
-                float4* sr = wb.srays + 3u * (size_t)item;
-                sr[0] = make_float4(pos.x, pos.y, pos.z, len);
-                sr[1] = make_float4(d.x, d.y, d.z, 0.0f);
-                sr[2] = make_float4(col.x, col.y, col.z, 0.0f);
-                wb.svis[item] = 1; // visible unless the traversal finds an occluder
+                if (late) {
+                    float4* sr = wb.srays + 3u * (size_t)item;
+                    sr[0] = make_float4(pos.x, pos.y, pos.z, len);
+                    sr[1] = make_float4(d.x, d.y, d.z, 0.0f);
+                    sr[2] = make_float4(col.x, col.y, col.z, 0.0f);
+                    wb.svis[item] = 1; // visible unless the traversal finds an occluder
+                } else {
+                    float4* sr = wb.srays + 2u * (size_t)item;
+                    sr[0] = make_float4(pos.x, pos.y, pos.z, len);
+                    sr[1] = make_float4(d.x, d.y, d.z, 0.0f);
+                    // the sample's light as if it arrived (src/light.cpp:171-186); the traversal clears it if not
+                    f3 c = { 0.0f, 0.0f, 0.0f };
+                    if (!isZero(col)) {
+                        const float4* a = wb.nodeA + 4u * (size_t)node;
+                        const float4 a1 = a[1], a2 = a[2], a3 = a[3];
+                        const f3 N = { a0.w, a1.x, a1.y }, rd = { a1.z, a1.w, a2.x }, kd = { a2.y, a2.z, a2.w }, ks = { a3.x, a3.y, a3.z };
+                        c = computeShading(ft, N, kd, ks, a3.w, -rd, -d, col);
+                    }
+                    float* dst = wb.contrib + 3u * (size_t)item;
+                    dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
+                }
             }
         }
     }
@@ -613,13 +642,13 @@ __global__ __launch_bounds__(kBlockThreads) void shadowTraceKernel(const DevScen
         bool want = !have && !dead;
         q.fetch(want, item, dead, &ctr->nextShadow, &ctr->dry[1], total, lane);
         if (!have && !dead && !want) {
-            const float4* sr = wb.srays + 3u * (size_t)item;
+            const float4* sr = wb.srays + (TRANSP ? 3u : 2u) * (size_t)item;
             const float4 a = sr[0], b = sr[1];
             if (a.w >= 0.0f) { // a negative length marks the slot of a node that holds no hit
                 tracer.launch(r, { a.x, a.y, a.z }, { b.x, b.y, b.z }, a.w, TRANSP ? K_SHADOW_CLOSEST : K_SHADOW_ANY);
                 have = true;
                 if (TRANSP) {
-                    curKd = ld3(wb.nodeB[item / wp.slots].mkd); // src/light.cpp:126
+                    curKd = ld3(wb.nodeB[fastDiv(item, wp.divSlots)].mkd); // src/light.cpp:126
                     tprod = 1.0f;
                 }
             }
@@ -630,11 +659,13 @@ __global__ __launch_bounds__(kBlockThreads) void shadowTraceKernel(const DevScen
             if (!TRANSP) {
                 // src/light.cpp:101-107
                 const bool visible = (r.hitPrim == kHitNone) ? true : (fabsf(r.tmax - r.slen) <= 0.0001f);
-                if (!visible)
-                    wb.svis[item] = 0;
+                if (!visible) {
+                    float* dst = wb.contrib + 3u * (size_t)item;
+                    dst[0] = dst[1] = dst[2] = 0.0f;
+                }
                 have = false;
             } else { // src/light.cpp:138-150
-                const float4 a0 = wb.nodeA[4u * (size_t)(item / wp.slots)];
+                const float4 a0 = wb.nodeA[4u * (size_t)fastDiv(item, wp.divSlots)];
                 const f3 P = { a0.x, a0.y, a0.z };
                 const f3 hp = r.o + r.tmax * r.d;
                 const bool atPoint = allEpsEq(hp, P, 0.0001f);
@@ -718,7 +749,7 @@ __global__ __launch_bounds__(256) void shadowShadeKernel(const DevScene sc, cons
         const f3 vis = wb.svis[item] ? mk3(col.x, col.y, col.z) : mk3(0.0f);
         if (!isZero(vis)) { // src/light.cpp:171-186
             const float4 d = sr[1];
-            const uint32_t node = item / wp.slots;
+            const uint32_t node = fastDiv(item, wp.divSlots);
             const float4* a = wb.nodeA + 4u * (size_t)node;
             const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
             f3 N = { a0.w, a1.x, a1.y };
@@ -859,7 +890,7 @@ __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const De
     __shared__ float vals[256 * 3];
     const uint32_t perRound = wp.R < 256u ? wp.R : 256u; // rays of one pixel handled side by side
     const uint32_t pixelsPerBlock = 256u / perRound;
-    const uint32_t pl = threadIdx.x / perRound, j = threadIdx.x % perRound;
+    const uint32_t pl = fastDiv(threadIdx.x, wp.divPerRound), j = threadIdx.x - pl * perRound;
     const uint32_t s = blockIdx.x * pixelsPerBlock + pl;
     int px = 0, py = 0;
     const bool valid = pl < pixelsPerBlock && s < wp.nSlots && slotToPixel(fr, wp.slotBegin + s, px, py);
@@ -937,7 +968,8 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, in
     hipLaunchKernelGGL(shadowVariant(stats, transp), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
     if (marks)
         (void)hipEventRecord(marks[2], stream);
-    hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
+    if (transp) // (otherwise the samples were shaded when they were generated)
+        hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
     const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
     if (transp)

@@ -46,6 +46,7 @@ struct WfParams {
     uint32_t nSlots;     // pixel slots in this batch (multiple of 64)
     uint32_t R;          // camera rays per pixel
     uint32_t slots;      // light-sample slots per hit: sum over lights of (point ? 1 : shadowSamples)
+    FastDiv divR, divSlots, divPerRound; // by R, by max(slots, 1), by min(R, 256)
     uint32_t drawsPerHit;
     uint32_t pixDraws;   // draws of the pixel-sample stretch
     uint32_t mainStart;  // position of the first light-sample draw
