@@ -326,7 +326,10 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
                         nb.depth = depth;
                         nb.childR = nb.childP = kChildNone;
                         nb.cvR[0] = nb.cvR[1] = nb.cvR[2] = 0.0f;
-                        nb.cvP[0] = nb.cvP[1] = nb.cvP[2] = 0.0f;
+                        if (TRANSP)
+                            nb.cvP[0] = nb.cvP[1] = nb.cvP[2] = 0.0f;
+                        else // no pass-through child: the slot carries ks, so that the combine reads one record per hit
+                            nb.cvP[0] = h.ks.x, nb.cvP[1] = h.ks.y, nb.cvP[2] = h.ks.z;
                         nb.tr = h.tr;
                         nb.mkd[0] = h.mkd.x, nb.mkd[1] = h.mkd.y, nb.mkd[2] = h.mkd.z;
                         nb.pad = 0u;
@@ -807,16 +810,12 @@ __device__ __forceinline__ f3 pathValue(const DevScene& sc, const DevFeat& ft, c
             break;
         cur = link;
     }
-    // deepest hit first
+    // deepest hit first (without transparency a hit's ks sits in its record's cvP slot)
     f3 v = nodeLo(sc, ft, wb, (uint32_t)chain[n - 1], wp.slots);
-    if (link == kChildMiss) {
-        const float4 a3 = wb.nodeA[4u * (size_t)chain[n - 1] + 3];
-        v = v + cv * mk3(a3.x, a3.y, a3.z);
-    }
-    for (int k = n - 2; k >= 0; k--) {
-        const float4 a3 = wb.nodeA[4u * (size_t)chain[k] + 3];
-        v = nodeLo(sc, ft, wb, (uint32_t)chain[k], wp.slots) + v * mk3(a3.x, a3.y, a3.z);
-    }
+    if (link == kChildMiss)
+        v = v + cv * ld3(wb.nodeB[chain[n - 1]].cvP);
+    for (int k = n - 2; k >= 0; k--)
+        v = nodeLo(sc, ft, wb, (uint32_t)chain[k], wp.slots) + v * ld3(wb.nodeB[chain[k]].cvP);
     return v;
 }
 

@@ -16,7 +16,7 @@ struct NodeB {
     int32_t childR;   // mirror child: kChildNone, kChildMiss (its value in cvR), or node index
     int32_t childP;   // pass-through child, likewise (cvP)
     float cvR[3];
-    float cvP[3];
+    float cvP[3];     // (without transparency: the hit's ks, read by the combine)
     float tr;         // material transparency
     float mkd[3];     // material kd (not the texture's): where the transparent shadow test starts, src/light.cpp:126
     uint32_t pad;
