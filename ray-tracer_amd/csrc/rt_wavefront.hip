@@ -139,61 +139,80 @@ __device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
 //     and only the others are queued for the traversal kernel, so its
 //     wavefronts spend their time on rays that have something to traverse.
 // ---------------------------------------------------------------------------
+constexpr uint32_t kCamPerLane = 4; // camera rays per lane: one queue reservation per 1 024 rays
+
 template <bool DOF>
 __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const DevCamera cam, const DevFeat ft, const DevFrame fr,
     const WfParams wp, const WfBuffers wb, DevCounters* __restrict__ ctr)
 {
-    __shared__ uint32_t waveCount[4];
+    __shared__ uint32_t waveCount[kCamPerLane][4];
     __shared__ uint32_t blockBase;
     const Tracer<false> tracer { sc, ft.accel, (LdsWords)0 };
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t total = wp.nSlots * wp.R;
-    const uint32_t path = blockIdx.x * blockDim.x + threadIdx.x;
-    bool queue = false, enters = false;
-    f3 o = { 0.0f, 0.0f, 0.0f }, d = { 0.0f, 0.0f, 0.0f };
-    if (path < total) {
-        const uint32_t pixel = fastDiv(path, wp.divR);
-        const uint32_t slot = wp.slotBegin + pixel, i = path - pixel * wp.R;
-        int px, py;
-        if (slotToPixel(fr, slot, px, py)) { // padding pixels of partial edge tiles have no rays
-            const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
-            const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
-            const uint32_t sample = (DOF && ft.dof) ? fastDiv(i, ft.divDof) : i; // i / dofN
-            uint32_t sPix = (ft.spp > 1) ? lcgSkip(seed, 2u * sample) : seed;
-            uint32_t sLens = (DOF && ft.dof) ? lcgSkip(seed, wp.pixDraws + 2u * i) : seed;
-            f3 pof = { 0.0f, 0.0f, 0.0f };
-            cameraRay<DOF>(cam, ft, fr, px, py, sample * dofN, sPix, sLens, pof, o, d);
-            enters = ft.accel && tracer.entersScene(o, rcp3(d));
-            // without the acceleration structure, or with spheres in the scene, every ray has work left
-            queue = enters || !ft.accel || sc.nSpheres != 0;
-            if (!queue) {
-                wb.pathHead[path] = kPathMiss;
-                wb.pathCount[path] = 0;
-                if (ft.envMap) {
-                    const f3 env = sampleEnvironmentMap(sc, ft, d);
-                    wb.pathEnv[3u * path + 0] = env.x;
-                    wb.pathEnv[3u * path + 1] = env.y;
-                    wb.pathEnv[3u * path + 2] = env.z;
+    bool queue[kCamPerLane], enters[kCamPerLane];
+    f3 o[kCamPerLane], d[kCamPerLane];
+    unsigned long long qm[kCamPerLane];
+#pragma unroll
+    for (uint32_t j = 0; j < kCamPerLane; j++) {
+        const uint32_t path = (blockIdx.x * kCamPerLane + j) * 256u + threadIdx.x;
+        queue[j] = enters[j] = false;
+        o[j] = d[j] = mk3(0.0f);
+        if (path < total) {
+            const uint32_t pixel = fastDiv(path, wp.divR);
+            const uint32_t slot = wp.slotBegin + pixel, i = path - pixel * wp.R;
+            int px, py;
+            if (slotToPixel(fr, slot, px, py)) { // padding pixels of partial edge tiles have no rays
+                const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
+                const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
+                const uint32_t sample = (DOF && ft.dof) ? fastDiv(i, ft.divDof) : i; // i / dofN
+                uint32_t sPix = (ft.spp > 1) ? lcgSkip(seed, 2u * sample) : seed;
+                uint32_t sLens = (DOF && ft.dof) ? lcgSkip(seed, wp.pixDraws + 2u * i) : seed;
+                f3 pof = { 0.0f, 0.0f, 0.0f };
+                cameraRay<DOF>(cam, ft, fr, px, py, sample * dofN, sPix, sLens, pof, o[j], d[j]);
+                enters[j] = ft.accel && tracer.entersScene(o[j], rcp3(d[j]));
+                // without the acceleration structure, or with spheres in the scene, every ray has work left
+                queue[j] = enters[j] || !ft.accel || sc.nSpheres != 0;
+                if (!queue[j]) {
+                    wb.pathHead[path] = kPathMiss;
+                    wb.pathCount[path] = 0;
+                    if (ft.envMap) {
+                        const f3 env = sampleEnvironmentMap(sc, ft, d[j]);
+                        wb.pathEnv[3u * path + 0] = env.x;
+                        wb.pathEnv[3u * path + 1] = env.y;
+                        wb.pathEnv[3u * path + 2] = env.z;
+                    }
                 }
             }
         }
+        qm[j] = __ballot(queue[j]);
+        if (lane == 0)
+            waveCount[j][wave] = (uint32_t)__popcll(qm[j]);
     }
     // one queue reservation per block
-    const unsigned long long qm = __ballot(queue);
-    if (lane == 0)
-        waveCount[wave] = (uint32_t)__popcll(qm);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t n = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
+        uint32_t n = 0;
+        for (uint32_t j = 0; j < kCamPerLane; j++)
+            n += waveCount[j][0] + waveCount[j][1] + waveCount[j][2] + waveCount[j][3];
         blockBase = n ? atomicAdd(&ctr->camQueued.v, n) : 0u;
     }
     __syncthreads();
-    if (queue) {
-        uint32_t idx = blockBase + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull));
-        for (uint32_t w = 0; w < wave; w++)
-            idx += waveCount[w];
-        wb.camRays[2u * (size_t)idx + 0] = make_float4(o.x, o.y, o.z, __uint_as_float(path));
-        wb.camRays[2u * (size_t)idx + 1] = make_float4(d.x, d.y, d.z, enters ? 1.0f : 0.0f);
+    uint32_t before = blockBase; // queued rays of the block before round j, wave `wave`
+#pragma unroll
+    for (uint32_t j = 0; j < kCamPerLane; j++) {
+        uint32_t idx = before + (uint32_t)__popcll(qm[j] & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < 4u; w++) {
+            const uint32_t c = waveCount[j][w];
+            if (w < wave)
+                idx += c;
+            before += c;
+        }
+        if (queue[j]) {
+            const uint32_t path = (blockIdx.x * kCamPerLane + j) * 256u + threadIdx.x;
+            wb.camRays[2u * (size_t)idx + 0] = make_float4(o[j].x, o[j].y, o[j].z, __uint_as_float(path));
+            wb.camRays[2u * (size_t)idx + 1] = make_float4(d[j].x, d[j].y, d[j].z, enters[j] ? 1.0f : 0.0f);
+        }
     }
 }
 
@@ -951,7 +970,7 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, in
     const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU)
 {
     // marks (optional, 3 events): after the path kernel, before and after the shadow-ray traversal
-    const int cb = (int)(((size_t)wp.nSlots * wp.R + 255) / 256);
+    const int cb = (int)(((size_t)wp.nSlots * wp.R + 256 * kCamPerLane - 1) / (256 * kCamPerLane));
     if (dof)
         hipLaunchKernelGGL(cameraKernel<true>, dim3(cb), dim3(256), 0, stream, sc, cam, ft, fr, wp, wb, ctr);
     else
