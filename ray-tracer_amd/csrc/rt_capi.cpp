@@ -86,6 +86,7 @@ struct rt_ctx {
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
     int pathBlocksPerCU = 0; // the same for the path kernel alone
+    int forcePathPerCU = 0, forceShadowPerCU = 0; // experiments: launch this many blocks per CU whatever the query says
     int forcePerPixel = 0; // 1 = always use the per-pixel kernel
     // 0 = traverse the caller's inner nodes as they are; 1 = own SAH hierarchy over the caller's leaves;
     // 2 = own SAH hierarchy over the caller's primitives, each a leaf of its own under its own box
@@ -177,6 +178,10 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->logicRounds = std::max(1, atoi(s));
     if (const char* s = getenv("RT_AMD_BLOCKS_PER_CU"))
         ctx->blocksPerCU = atoi(s);
+    if (const char* s = getenv("RT_AMD_FORCE_PATH_PER_CU"))
+        ctx->forcePathPerCU = atoi(s);
+    if (const char* s = getenv("RT_AMD_FORCE_SHADOW_PER_CU"))
+        ctx->forceShadowPerCU = atoi(s);
     if (const char* s = getenv("RT_AMD_PATH_BLOCKS_PER_CU"))
         ctx->pathBlocksPerCU = atoi(s);
     if (const char* s = getenv("RT_AMD_TREE"))
@@ -1069,6 +1074,10 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         }
         if (ctx->pathBlocksPerCU > 0)
             pathPerCU = std::min(pathPerCU, ctx->pathBlocksPerCU);
+        if (ctx->forcePathPerCU > 0) // experiments: more blocks than the occupancy query answers
+            pathPerCU = std::min(ctx->forcePathPerCU, maxPerCU);
+        if (ctx->forceShadowPerCU > 0)
+            shadowPerCU = std::min(ctx->forceShadowPerCU, maxPerCU);
         // every wavefront of the path kernel may leave part of its last block of node slots unused
         const uint64_t nodeSlack = static_cast<uint64_t>(ctx->numCU) * pathPerCU * (blockThreads / 64) * kNodeBlock;
         // Hits one camera ray can make.  A hit below the depth cap has a mirror child if its material

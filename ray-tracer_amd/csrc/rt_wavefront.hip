@@ -139,7 +139,10 @@ __device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
 //     and only the others are queued for the traversal kernel, so its
 //     wavefronts spend their time on rays that have something to traverse.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kCamPerLane = 4; // camera rays per lane: one queue reservation per 1 024 rays
+#ifndef RT_CAM_PER_LANE
+#define RT_CAM_PER_LANE 4
+#endif
+constexpr uint32_t kCamPerLane = RT_CAM_PER_LANE; // camera rays per lane: one queue reservation per 256 times as many rays
 
 template <bool DOF>
 __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const DevCamera cam, const DevFeat ft, const DevFrame fr,
