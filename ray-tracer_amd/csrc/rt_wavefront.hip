@@ -11,17 +11,23 @@
 // chain root first) owns draws [main + D*k, main + D*(k+1)).  That turns the
 // frame into independent work items, each on its own lane:
 //
-//   1. pathKernel    one lane per camera ray: trace it and its mirror chain
-//                    (src/recursive.cpp:25-64), append one node per hit;
+//   1. cameraKernel  one lane per camera ray: generate it, test it against the scene's
+//                    box, finish the ones that miss it and queue the others;
+//      pathKernel    the queued rays: trace each and the rays its hits spawn (the mirror
+//                    chain, with transparency the tree of mirror and pass-through rays,
+//                    src/recursive.cpp:25-64), append one node per hit;
 //   2. prefixKernel  per pixel, exclusive prefix of its paths' hit counts;
-//   3. shadowKernel  one lane per (hit, light sample): jump the LCG to the
-//                    sample's draws, sample the light, trace the shadow ray
-//                    (any-hit), shade (src/light.cpp:166-186);
-//   4. combineKernel per pixel: sums, clamp and mirror combine in exactly the
-//                    reference's order of operations, then the pixel mean.
+//   3. shadowGenKernel    one lane per (hit, light sample): jump the LCG to the sample's
+//                         draws, sample the light, build the shadow ray, shade the sample;
+//      shadowTraceKernel  trace the shadow rays (any-hit; closest-hit through
+//                         non-opaque surfaces with transparency), clear what is occluded;
+//      shadowShadeKernel  with transparency only, where the light is tinted on its way:
+//                         shade the samples after the traversal (src/light.cpp:166-186);
+//   4. combineKernel per pixel: sums, clamp and mirror / pass-through combine in exactly
+//                    the reference's order of operations, then the pixel mean.
 //
-// Kernels 1 and 3 are persistent 64-lane wavefronts pulling batches of work
-// items from an atomic queue; lanes whose ray has finished take their next
+// pathKernel and shadowTraceKernel are persistent 64-lane wavefronts pulling batches of
+// work items from an atomic queue; lanes whose ray has finished take their next
 // item while the others keep traversing (rt_trace.hpp).  All arithmetic is the
 // same as in the per-pixel kernel of rt_kernels.hip, in the same order, so
 // both produce the same bits.
@@ -503,12 +509,14 @@ __global__ void prefixKernel(const DevFrame fr, const WfParams wp, const WfBuffe
 
 // ---------------------------------------------------------------------------
 // 3. one light sample of one hit: computeContributionPointLight, src/light.cpp:166-186,
-//    in three kernels so that the divergent part (the traversal) carries nothing
-//    but the ray: (a) sample the light and build the shadow ray, one lane per
-//    (hit, sample), fully coherent; (b) any-hit traversal, persistent wavefronts
-//    pulling batches of rays from an atomic queue (every ray ends on a surface,
-//    so every ray enters the scene's box: nothing to compact away);
-//    (c) shade the visible samples, one lane per (hit, sample) again.
+//    in separate kernels so that the divergent part (the traversal) carries nothing
+//    but the ray: (a) sample the light, build the shadow ray and, without transparency,
+//    shade the sample as if its light arrived, one lane per (hit, sample), fully
+//    coherent; (b) any-hit traversal, persistent wavefronts pulling batches of rays
+//    from an atomic queue (every ray ends on a surface, so every ray enters the scene's
+//    box: nothing to compact away), which clears the contribution of an occluded
+//    sample; (c) with transparency only: shade the samples with the light that got
+//    through, one lane per (hit, sample) again.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp,
     const WfBuffers wb, DevCounters* __restrict__ ctr, const rt_light* __restrict__ lightsGlobal)
