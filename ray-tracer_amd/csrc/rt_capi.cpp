@@ -562,10 +562,14 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
             }
             leaves.push_back(l);
         }
+        // Full-sweep SAH build in O(n log n): the leaves are sorted by centre once per axis; a
+        // node owns the same range [b, e) of all three orders, sweeps each for the cheapest split,
+        // and hands its halves down by a stable partition of the other two orders.
         struct Build {
             std::vector<Leaf>& L;
             std::vector<uint4>& pairs;
-            std::vector<uint32_t> idx, tmp;
+            std::vector<uint32_t> order[3], tmp, suffixCount;
+            std::vector<uint8_t> goesLeft;
             std::vector<float> rightArea;
             uint32_t maxDepth = 0;
             decltype(packBox)& pack;
@@ -574,8 +578,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
                 const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
                 return 2.0f * (x * y + x * z + y * z);
             }
-            void bounds(uint32_t b, uint32_t e, float* lo, float* hi)
+            void bounds(uint32_t b, uint32_t e, float* lo, float* hi) const
             {
+                const std::vector<uint32_t>& idx = order[0];
                 for (int a = 0; a < 3; a++)
                     lo[a] = L[idx[b]].lo[a], hi[a] = L[idx[b]].hi[a];
                 for (uint32_t i = b + 1; i < e; i++)
@@ -584,23 +589,40 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
                         hi[a] = std::max(hi[a], L[idx[i]].hi[a]);
                     }
             }
-            // returns the child reference of the subtree over idx[b, e)
+            void start()
+            {
+                const uint32_t n = static_cast<uint32_t>(L.size());
+                for (int axis = 0; axis < 3; axis++) {
+                    order[axis].resize(n);
+                    for (uint32_t i = 0; i < n; i++)
+                        order[axis][i] = i;
+                    std::sort(order[axis].begin(), order[axis].end(), [&](uint32_t x, uint32_t y) {
+                        return L[x].c[axis] < L[y].c[axis] || (L[x].c[axis] == L[y].c[axis] && x < y);
+                    });
+                }
+                goesLeft.assign(n, 0);
+                tmp.resize(n);
+                rightArea.resize(n);
+                suffixCount.resize(n + 1);
+            }
+            // returns the child reference of the subtree over the range [b, e) of the three orders
             uint32_t build(uint32_t b, uint32_t e, uint32_t depth)
             {
                 maxDepth = std::max(maxDepth, depth);
                 if (e - b == 1)
-                    return L[idx[b]].ref;
+                    return L[order[0][b]].ref;
                 const uint32_t n = e - b;
                 float bestCost = std::numeric_limits<float>::infinity();
                 int bestAxis = -1;
                 uint32_t bestSplit = 0;
                 for (int axis = 0; axis < 3; axis++) {
-                    std::sort(idx.begin() + b, idx.begin() + e, [&](uint32_t x, uint32_t y) { return L[x].c[axis] < L[y].c[axis]; });
+                    const uint32_t* idx = order[axis].data() + b;
                     float lo[3], hi[3];
-                    rightArea.resize(n);
                     uint32_t cnt = 0;
-                    for (uint32_t i = n; i-- > 1;) { // suffix boxes
-                        const Leaf& q = L[idx[b + i]];
+                    suffixCount[n] = 0;
+                    for (uint32_t i = n; i-- > 0;) { // suffix boxes and primitive counts
+                        const Leaf& q = L[idx[i]];
+                        suffixCount[i] = suffixCount[i + 1] + q.count;
                         if (i == n - 1)
                             for (int a = 0; a < 3; a++)
                                 lo[a] = q.lo[a], hi[a] = q.hi[a];
@@ -609,12 +631,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
                                 lo[a] = std::min(lo[a], q.lo[a]), hi[a] = std::max(hi[a], q.hi[a]);
                         rightArea[i] = area(lo, hi);
                     }
-                    std::vector<uint32_t>& suffixCount = tmp;
-                    suffixCount.assign(n + 1, 0);
-                    for (uint32_t i = n; i-- > 0;)
-                        suffixCount[i] = suffixCount[i + 1] + L[idx[b + i]].count;
                     for (uint32_t i = 0; i + 1 < n; i++) { // split after element i
-                        const Leaf& q = L[idx[b + i]];
+                        const Leaf& q = L[idx[i]];
                         if (i == 0)
                             for (int a = 0; a < 3; a++)
                                 lo[a] = q.lo[a], hi[a] = q.hi[a];
@@ -632,8 +650,22 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
                     bestAxis = 0;
                     bestSplit = n / 2;
                 }
-                std::sort(idx.begin() + b, idx.begin() + e, [&](uint32_t x, uint32_t y) { return L[x].c[bestAxis] < L[y].c[bestAxis]; });
                 const uint32_t mid = b + bestSplit;
+                for (uint32_t i = b; i < e; i++)
+                    goesLeft[order[bestAxis][i]] = i < mid;
+                for (int axis = 0; axis < 3; axis++) {
+                    if (axis == bestAxis)
+                        continue;
+                    uint32_t* idx = order[axis].data();
+                    uint32_t nl = b, nr = 0;
+                    for (uint32_t i = b; i < e; i++) {
+                        if (goesLeft[idx[i]])
+                            idx[nl++] = idx[i];
+                        else
+                            tmp[nr++] = idx[i];
+                    }
+                    std::copy(tmp.begin(), tmp.begin() + nr, idx + nl);
+                }
                 const size_t me = pairs.size();
                 pairs.resize(me + 2);
                 float lo[3], hi[3];
@@ -649,10 +681,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
                 return static_cast<uint32_t>(me / 2);
             }
         };
-        Build bld { leaves, pairs, {}, {}, {}, 0, packBox };
-        bld.idx.resize(leaves.size());
-        for (uint32_t i = 0; i < leaves.size(); i++)
-            bld.idx[i] = i;
+        Build bld { leaves, pairs, {}, {}, {}, {}, {}, 0, packBox };
+        bld.start();
         pairs.reserve(leaves.size() * 2);
         rootRef = bld.build(0, static_cast<uint32_t>(leaves.size()), 1);
         if (bld.maxDepth + 1 <= (uint32_t)kMaxStack) {
