@@ -208,13 +208,7 @@ struct Tracer {
             tRun = clock64();
         }
         for (;;) {
-            if ((int32_t)r.cur < 0 && r.pend == 0u) { // a leaf and a free slot: park it, take the next node
-                const uint32_t count = (r.cur >> 27) & 15u, first = r.cur & kLeafOffsetMask;
-                r.pend = count ? r.cur : 0u; // an empty leaf is dropped here
-                r.li = (first << 2) + (first << 1);
-                r.le = r.li + (count << 2) + (count << 1);
-                r.cur = pop(r);
-            }
+            park(r);
             // every lane with a ray in flight can take an inner step, a triangle test, or both:
             // a lane whose node is a second leaf holds a parked one
             const bool canInner = r.cur < kRefNone; // leaf refs have the top bit set, kRefNone is the largest inner value
@@ -255,6 +249,18 @@ struct Tracer {
         if (STATS)
             r.cycRun += (unsigned long long)(clock64() - tRun);
         r.active = r.pend != 0u || r.cur != kRefNone;
+    }
+
+    // A lane whose node is a leaf, with its slot for one free: park the leaf, take the next node.
+    __device__ __forceinline__ void park(RayState& r) const
+    {
+        if ((int32_t)r.cur < 0 && r.pend == 0u) {
+            const uint32_t count = (r.cur >> 27) & 15u, first = r.cur & kLeafOffsetMask;
+            r.pend = count ? r.cur : 0u; // an empty leaf is dropped here
+            r.li = (first << 2) + (first << 1);
+            r.le = r.li + (count << 2) + (count << 1);
+            r.cur = pop(r);
+        }
     }
 
     // One sibling-pair record (32 B): test both children, descend into the nearer.
