@@ -77,11 +77,12 @@ struct rt_ctx {
     bool haveFeatures = false;
     // tuning knobs of the render kernel (environment-overridable for experiments)
     int minActive = 32;       // per-pixel and path kernels: leave the traversal loop below this many rays in flight
-    int minActiveShadow = 48; // shadow-ray kernel (its refill is cheap)
+    int minActiveShadow = 32; // shadow-ray kernel
     // switch points of the traversal loop between inner steps and triangle tests (rt_trace.hpp):
     // lanes blocked before triangles are tested; lanes still holding a leaf when inner steps resume
     int parkA = 16, parkB = 32, parkAShadow = 16, parkBShadow = 32;
     int chunkPath = 128, chunkShadow = 512; // rays a wavefront takes from the queue at a time
+    int leastPath = 32;                     // the least the path kernel takes (small frames)
     int ownShare = 0;                       // sixteenths of a queue its waves split up by position (beyond the first batch)
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
@@ -170,6 +171,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->parkBShadow = atoi(s);
     if (const char* s = getenv("RT_AMD_CHUNK_PATH"))
         ctx->chunkPath = std::max(64, atoi(s));
+    if (const char* s = getenv("RT_AMD_LEAST_PATH"))
+        ctx->leastPath = std::min(64, std::max(1, atoi(s)));
     if (const char* s = getenv("RT_AMD_OWN_SHARE"))
         ctx->ownShare = std::min(16, std::max(0, atoi(s)));
     if (const char* s = getenv("RT_AMD_CHUNK_SHADOW"))
@@ -1088,6 +1091,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         wp.mainStart = wp.pixDraws + (F.enableDepthOfField ? 2u * ft.camRays * F.numDepthOfFieldSamples : 0u);
         wp.chunk = ctx->chunkShadow;
         wp.chunkPath = ctx->chunkPath;
+        wp.leastPath = ctx->leastPath;
+        wp.nodeBlockFixed = getenv("RT_AMD_NODE_BLOCK_FIXED") ? 1u : 0u;
         wp.ownShare = ctx->ownShare;
         if (wp.R == 0 || wp.R > 65535u)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);

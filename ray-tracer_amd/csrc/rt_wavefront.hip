@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
     // node slots a wave reserves per atomic: about what its share of the rays will fill, so that a small
     // frame does not leave most of the pool's touched part empty (every slot is a work item further on)
     uint32_t nodeBlock = kNodeBlock;
-    while (nodeBlock > 64u && nodeBlock * (gridDim.x * (blockDim.x / 64u)) > 2u * total)
+    while (wp.nodeBlockFixed == 0u && nodeBlock > 64u && nodeBlock * (gridDim.x * (blockDim.x / 64u)) > 2u * total)
         nodeBlock >>= 1;
 
     RayState r;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
     bool viaPass = false; // the ray in flight is the pass-through child of `prev` (else its mirror child)
     bool have = false, dead = false;
     WaveQueue q;
-    q.start(total, wp.ownShare, wp.chunkPath, 32u);
+    q.start(total, wp.ownShare, wp.chunkPath, wp.leastPath);
 
     for (;;) {
         // ---- lanes without a path take the next queued camera ray
