@@ -78,6 +78,16 @@ def test_host_sah_binned_bvh_equals_oracle(name):
     assert n1.tobytes() != nm.tobytes() or len(prims) <= 4  # not the median tree
 
 
+def test_fast_division_is_exact(tmp_path):
+    """The multiply-high division the kernels use for per-launch divisors (rays per pixel, light samples
+    per hit, lens samples, tiles per row) against the machine's own: every divisor up to 70 000 with edge
+    and random dividends, and random divisors of every magnitude."""
+    exe = str(tmp_path / "fastdiv_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(common.ROOT, "tests", "cpp", "fastdiv_check.cpp")], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("0 wrong"), out.stdout
+
+
 def test_shard_floats_matches_python_layout():
     for (w, h) in [(1920, 1080), (17, 9), (8, 8), (3840, 2160), (100, 1)]:
         for world in (1, 2, 3, 4, 8):
