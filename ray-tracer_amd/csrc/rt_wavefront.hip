@@ -32,6 +32,8 @@
 // same as in the per-pixel kernel of rt_kernels.hip, in the same order, so
 // both produce the same bits.
 
+#include <cstdio>
+#include <cstdlib>
 #include "rt_trace.hpp"
 #include "rt_wavefront.hpp"
 
@@ -643,8 +645,13 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
 // TRANSP: testVisibilityLightSampleTransparency (src/light.cpp:112-151) instead of the binary
 // test: the closest hit along the ray; a hit short of the shaded point on a material that is
 // not opaque tints the light and the ray goes on from there.
+#ifdef RT_SHADOW_WAVES // experiments: force the register budget of this many waves per SIMD
+#define RT_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WAVES, RT_SHADOW_WAVES)))
+#else
+#define RT_SHADOW_ATTR
+#endif
 template <bool STATS, bool TRANSP>
-__global__ __launch_bounds__(kBlockThreads) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+__global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
@@ -973,6 +980,18 @@ hipError_t wavefrontOccupancy(bool stats, bool transp, int blockThreads, size_t 
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(pathBlocks, pathVariant(stats, transp), blockThreads, ldsBytes);
     if (e != hipSuccess)
         return e;
+    if (getenv("RT_AMD_DEBUG_OCCUPANCY")) { // what bounds the resident blocks: registers or LDS
+        for (int k = 0; k < 2; k++) {
+            const void* fn = k ? (const void*)shadowVariant(stats, transp) : (const void*)pathVariant(stats, transp);
+            hipFuncAttributes a {};
+            int noLds = 0, withLds = 0;
+            (void)hipFuncGetAttributes(&a, fn);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&noLds, fn, blockThreads, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&withLds, fn, blockThreads, ldsBytes);
+            fprintf(stderr, "[rt_amd] %s kernel: %d registers, %zu B static LDS, %zu B dynamic: %d blocks per CU without the dynamic LDS, %d with\n",
+                k ? "shadow" : "path", a.numRegs, a.sharedSizeBytes, ldsBytes, noLds, withLds);
+        }
+    }
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(shadowBlocks, shadowVariant(stats, transp), blockThreads, ldsBytes);
 }
 
