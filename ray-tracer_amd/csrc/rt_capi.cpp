@@ -83,6 +83,7 @@ struct rt_ctx {
     int parkA = 16, parkB = 32, parkAShadow = 16, parkBShadow = 32;
     int chunkPath = 128, chunkShadow = 512; // rays a wavefront takes from the queue at a time
     int leastPath = 32;                     // the least the path kernel takes (small frames)
+    int nodeBlockFixed = 0;                 // experiments: node blocks of full size whatever the frame's size
     int ownShare = 0;                       // sixteenths of a queue its waves split up by position (beyond the first batch)
     int logicRounds = 2;
     int blocksPerCU = 0; // 0 = ask the occupancy API
@@ -171,6 +172,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->parkBShadow = atoi(s);
     if (const char* s = getenv("RT_AMD_CHUNK_PATH"))
         ctx->chunkPath = std::max(64, atoi(s));
+    if (getenv("RT_AMD_NODE_BLOCK_FIXED"))
+        ctx->nodeBlockFixed = 1;
     if (const char* s = getenv("RT_AMD_LEAST_PATH"))
         ctx->leastPath = std::min(64, std::max(1, atoi(s)));
     if (const char* s = getenv("RT_AMD_OWN_SHARE"))
@@ -1092,7 +1095,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         wp.chunk = ctx->chunkShadow;
         wp.chunkPath = ctx->chunkPath;
         wp.leastPath = ctx->leastPath;
-        wp.nodeBlockFixed = getenv("RT_AMD_NODE_BLOCK_FIXED") ? 1u : 0u;
+        wp.nodeBlockFixed = ctx->nodeBlockFixed ? 1u : 0u;
         wp.ownShare = ctx->ownShare;
         if (wp.R == 0 || wp.R > 65535u)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
