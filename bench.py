@@ -45,9 +45,9 @@ sys.path.insert(0, ROOT)
 # With N > 1 the collective library's own stream joins the frames' streams; HIP maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams on one queue run one after the
 # other (measured at N = 1: a fourth frame in flight on four queues costs 12 %, on eight it does not).
-# Has to be set before the HIP runtime starts; an explicit setting wins.
+# Has to be set before the HIP runtime starts; RT_BENCH_HW_QUEUES overrides the 8.
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "8")
 
 sio = importlib.import_module("ray-tracer_amd.scene_io")
 capi = importlib.import_module("ray-tracer_amd.capi")
