@@ -15,7 +15,7 @@ data-path collective), the only collective is the RCCL gather of the packed
 tile buffers to rank 0, which scatters them into Screen order.  The frame is
 the same whatever N is, so scaling is "strong".
 
-Frames in flight: consecutive steps go round-robin to `--in-flight` (default 3) contexts, each
+Frames in flight: consecutive steps go round-robin to `--in-flight` (default 3, 4 when N > 1) contexts, each
 with its own stream, workspace and output buffers, the way a double- or triple-buffered
 renderer runs.  Every frame is still rendered, gathered and post-processed completely; the
 persistent traversal kernels of one frame merely start on the compute units the previous
@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--cpu-scale", type=int, default=2)
     ap.add_argument("--camera-distance", type=float, default=3.0,
                     help="the reference's default camera is at 3.0 (src/config.h:18-23); 1.6 fills the frame with the model")
-    ap.add_argument("--in-flight", type=int, default=3, help="frames in flight (contexts/streams used round-robin)")
+    ap.add_argument("--in-flight", type=int, default=0, help="frames in flight (contexts/streams used round-robin)")
     args = ap.parse_args()
 
     import torch
@@ -178,7 +178,9 @@ def main():
     if args.camera_distance != 3.0:
         desc += f" [camera distance {args.camera_distance} instead of the default 3.0]"
 
-    lanes = max(1, args.in_flight)
+    # three at N = 1 (a fourth context's worst-case workspace does not fit beside the others at the
+    # headline size); four on a shard, where they fit and the fixed part of a frame weighs more
+    lanes = args.in_flight if args.in_flight > 0 else (3 if world == 1 else 4)
     stride = capi.shard_floats(width, height, 0, world)
     ctxs, streams, frames, packeds, gathereds = [], [], [], [], []
     for _ in range(lanes):
