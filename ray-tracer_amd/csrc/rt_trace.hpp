@@ -338,12 +338,17 @@ __device__ __forceinline__ HitCtx shadeHit(const DevScene& sc, const DevFeat& ft
     DevMaterial m;
     if (r.hitPrim >= 0) {
         const uint32_t i = (uint32_t)r.hitPrim;
-        const TriRec tr = loadTri(sc.tris, i);
-        const float4 a0 = sc.attrs[4u * i + 0], a1 = sc.attrs[4u * i + 1], a2 = sc.attrs[4u * i + 2], a3 = sc.attrs[4u * i + 3];
+        // flat, untextured shading needs the plane's normal and the mesh id only; the vertices and
+        // their attributes are loaded where interpolation asks for them
+        const float4 plane = sc.tris[6u * i];
+        const float4 a3 = sc.attrs[4u * i + 3];
         m = sc.mats[__float_as_uint(a3.w)];
-        f3 N = tr.n;
+        const f3 planeN = { plane.x, plane.y, plane.z };
+        f3 N = planeN;
         f2 uv = { 0.0f, 0.0f };
         if (ft.normalInterp || ft.texMapping) {
+            const TriRec tr = loadTri(sc.tris, i);
+            const float4 a0 = sc.attrs[4u * i + 0], a1 = sc.attrs[4u * i + 1], a2 = sc.attrs[4u * i + 2];
             // computeBarycentricCoord, src/interpolate.cpp:13-24
             const f3 n = cross(tr.v1 - tr.v0, tr.v2 - tr.v0);
             const f3 na = cross(tr.v2 - tr.v1, h.P - tr.v1);
@@ -358,7 +363,7 @@ __device__ __forceinline__ HitCtx shadeHit(const DevScene& sc, const DevFeat& ft
                 uv.y = a2.z * alpha + a3.x * beta + a3.z * gamma;
             }
         }
-        if (dot(r.d, tr.n) > 0.0f)
+        if (dot(r.d, planeN) > 0.0f)
             N = -N;
         h.N = N;
         h.kd = (ft.texMapping && m.tex >= 0) ? sampleTexture(sc, m.tex, uv, ft.bilinear != 0) : ld3(m.kd);
