@@ -190,8 +190,13 @@ int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_n
  * scene.meshes[i].material, the textures they name, the six
  * environmentMapTextures (src/scene.h:40-48; image index or -1) and
  * scene.spheres.  All host memory stays caller-owned and is copied; the
- * device layout is built here.  generation (optional) receives a counter that
- * changes with every upload. */
+ * device layout is built here.  The caller's nodes are validated and define
+ * which primitives exist and in which order; the rays are walked through a
+ * hierarchy of the library's own over those primitives (which primitive a ray
+ * hits and its t do not depend on the hierarchy; of two primitives hit at
+ * exactly the same t the one with the higher index is reported, as the
+ * reference does inside a leaf).  generation (optional) receives a counter
+ * that changes with every upload. */
 int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const rt_primitive* prims,
                     uint32_t n_prims, const rt_material* mesh_materials, uint32_t n_meshes,
                     const rt_image* images, uint32_t n_images, const int32_t env_faces[6],
