@@ -39,6 +39,44 @@ using namespace rt;
 
 static thread_local std::string g_lastError;
 
+struct TreeLeaf {
+    float lo[3], hi[3], c[3];
+    uint32_t ref, count;
+};
+
+// Quantisation grid: 65535 cells per axis across the root box.  A plane q stands
+// for the real number gridMin + q * gridCell (both floats); lower planes round
+// down, upper planes round up, checked in double so the quantised box contains
+// the float box whatever the rounding of the division did.
+struct QuantGrid {
+    float gridMin[3], gridCell[3];
+    uint32_t quantLo(float v, int a) const
+    {
+        if (!(gridCell[a] > 0.0f))
+            return 0u;
+        double q = std::floor((static_cast<double>(v) - gridMin[a]) / gridCell[a]);
+        q = std::min(65535.0, std::max(0.0, q));
+        while (q > 0.0 && static_cast<double>(gridMin[a]) + q * gridCell[a] > static_cast<double>(v))
+            q -= 1.0;
+        return static_cast<uint32_t>(q);
+    }
+    uint32_t quantHi(float v, int a) const
+    {
+        if (!(gridCell[a] > 0.0f))
+            return 65535u; // flat or empty axis: A = 0, every plane sits at gridMin
+        double q = std::ceil((static_cast<double>(v) - gridMin[a]) / gridCell[a]);
+        q = std::min(65535.0, std::max(0.0, q));
+        while (q < 65535.0 && static_cast<double>(gridMin[a]) + q * gridCell[a] < static_cast<double>(v))
+            q += 1.0;
+        return static_cast<uint32_t>(q);
+    }
+    void packBox(const float* lo, const float* hi, uint32_t* w) const
+    {
+        for (int a = 0; a < 3; a++)
+            w[a] = quantLo(lo[a], a) | (quantHi(hi[a], a) << 16);
+    }
+};
+
 struct rt_ctx {
     int device = 0;
     int numCU = 256;
@@ -241,6 +279,179 @@ struct KeyIdx {
     float key;
     uint32_t idx;
 };
+
+// ---------------------------------------------------------------------------
+// The library's own traversal hierarchy (see rt_scene_upload)
+// ---------------------------------------------------------------------------
+// Full-sweep SAH build in O(n log n): the leaves are sorted by centre once per axis; a
+// node owns the same range [b, e) of all three orders, sweeps each for the cheapest split,
+// and hands its halves down by a stable partition of the other two orders.
+struct TreeBuild {
+    const std::vector<TreeLeaf>& L;
+    std::vector<uint4>& pairs;
+    const QuantGrid& grid;
+    std::vector<uint32_t> order[3], tmp, suffixCount;
+    std::vector<uint8_t> goesLeft;
+    std::vector<float> rightArea;
+    uint32_t maxDepth = 0;
+
+    TreeBuild(const std::vector<TreeLeaf>& leaves, std::vector<uint4>& out, const QuantGrid& g)
+        : L(leaves), pairs(out), grid(g)
+    {
+    }
+    float area(const float* lo, const float* hi) const
+    {
+        const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return 2.0f * (x * y + x * z + y * z);
+    }
+    void pack(const float* lo, const float* hi, uint32_t* w) const { grid.packBox(lo, hi, w); }
+    void bounds(uint32_t b, uint32_t e, float* lo, float* hi) const
+    {
+        const std::vector<uint32_t>& idx = order[0];
+        for (int a = 0; a < 3; a++)
+            lo[a] = L[idx[b]].lo[a], hi[a] = L[idx[b]].hi[a];
+        for (uint32_t i = b + 1; i < e; i++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = std::min(lo[a], L[idx[i]].lo[a]);
+                hi[a] = std::max(hi[a], L[idx[i]].hi[a]);
+            }
+    }
+    void start()
+    {
+        const uint32_t n = static_cast<uint32_t>(L.size());
+        for (int axis = 0; axis < 3; axis++) {
+            order[axis].resize(n);
+            for (uint32_t i = 0; i < n; i++)
+                order[axis][i] = i;
+            std::sort(order[axis].begin(), order[axis].end(), [&](uint32_t x, uint32_t y) {
+                return L[x].c[axis] < L[y].c[axis] || (L[x].c[axis] == L[y].c[axis] && x < y);
+            });
+        }
+        goesLeft.assign(n, 0);
+        tmp.resize(n);
+        rightArea.resize(n);
+        suffixCount.resize(n + 1);
+    }
+    // returns the child reference of the subtree over the range [b, e) of the three orders
+    uint32_t build(uint32_t b, uint32_t e, uint32_t depth)
+    {
+        maxDepth = std::max(maxDepth, depth);
+        if (e - b == 1)
+            return L[order[0][b]].ref;
+        const uint32_t n = e - b;
+        float bestCost = std::numeric_limits<float>::infinity();
+        int bestAxis = -1;
+        uint32_t bestSplit = 0;
+        for (int axis = 0; axis < 3; axis++) {
+            const uint32_t* idx = order[axis].data() + b;
+            float lo[3], hi[3];
+            uint32_t cnt = 0;
+            suffixCount[n] = 0;
+            for (uint32_t i = n; i-- > 0;) { // suffix boxes and primitive counts
+                const TreeLeaf& q = L[idx[i]];
+                suffixCount[i] = suffixCount[i + 1] + q.count;
+                if (i == n - 1)
+                    for (int a = 0; a < 3; a++)
+                        lo[a] = q.lo[a], hi[a] = q.hi[a];
+                else
+                    for (int a = 0; a < 3; a++)
+                        lo[a] = std::min(lo[a], q.lo[a]), hi[a] = std::max(hi[a], q.hi[a]);
+                rightArea[i] = area(lo, hi);
+            }
+            for (uint32_t i = 0; i + 1 < n; i++) { // split after element i
+                const TreeLeaf& q = L[idx[i]];
+                if (i == 0)
+                    for (int a = 0; a < 3; a++)
+                        lo[a] = q.lo[a], hi[a] = q.hi[a];
+                else
+                    for (int a = 0; a < 3; a++)
+                        lo[a] = std::min(lo[a], q.lo[a]), hi[a] = std::max(hi[a], q.hi[a]);
+                cnt += q.count;
+                const float cost = area(lo, hi) * (float)std::max(1u, cnt) + rightArea[i + 1] * (float)std::max(1u, suffixCount[i + 1]);
+                if (cost < bestCost)
+                    bestCost = cost, bestAxis = axis, bestSplit = i + 1;
+            }
+        }
+        // keep the depth bounded: fall back to the middle once a branch runs deep
+        if (bestAxis < 0 || depth + 2 + (uint32_t)std::ceil(std::log2((double)n)) > (uint32_t)kMaxStack) {
+            bestAxis = 0;
+            bestSplit = n / 2;
+        }
+        const uint32_t mid = b + bestSplit;
+        for (uint32_t i = b; i < e; i++)
+            goesLeft[order[bestAxis][i]] = i < mid;
+        for (int axis = 0; axis < 3; axis++) {
+            if (axis == bestAxis)
+                continue;
+            uint32_t* idx = order[axis].data();
+            uint32_t nl = b, nr = 0;
+            for (uint32_t i = b; i < e; i++) {
+                if (goesLeft[idx[i]])
+                    idx[nl++] = idx[i];
+                else
+                    tmp[nr++] = idx[i];
+            }
+            std::copy(tmp.begin(), tmp.begin() + nr, idx + nl);
+        }
+        const size_t me = pairs.size();
+        pairs.resize(me + 2);
+        float lo[3], hi[3];
+        uint32_t wl[3], wr[3];
+        bounds(b, mid, lo, hi);
+        pack(lo, hi, wl);
+        bounds(mid, e, lo, hi);
+        pack(lo, hi, wr);
+        const uint32_t rl = build(b, mid, depth + 1);
+        const uint32_t rr = build(mid, e, depth + 1);
+        pairs[me] = make_uint4(wl[0], wl[1], wl[2], wr[0]);
+        pairs[me + 1] = make_uint4(wr[1], wr[2], rl, rr);
+        return static_cast<uint32_t>(me / 2);
+    }
+};
+
+// Builds the hierarchy over `leaves` into sibling-pair records in breadth-first order (the records
+// every ray starts with sit next to each other).  False if it came out deeper than a traversal stack.
+static bool buildOwnTree(const std::vector<TreeLeaf>& leaves, const QuantGrid& grid, std::vector<uint4>& pairs, uint32_t& rootRef,
+    uint32_t& levels)
+{
+    pairs.clear();
+    TreeBuild bld(leaves, pairs, grid);
+    bld.start();
+    pairs.reserve(leaves.size() * 2);
+    rootRef = bld.build(0, static_cast<uint32_t>(leaves.size()), 1);
+    if (bld.maxDepth + 1 > (uint32_t)kMaxStack) {
+        pairs.clear();
+        return false;
+    }
+    levels = bld.maxDepth; // nodes on the longest path from the root to a leaf, as for the caller's tree
+    if ((rootRef & kLeafFlag) == 0) {
+        const uint32_t nPairs = static_cast<uint32_t>(pairs.size() / 2);
+        std::vector<uint32_t> order, newIndex(nPairs, 0);
+        order.reserve(nPairs);
+        order.push_back(rootRef);
+        for (size_t h = 0; h < order.size(); h++) {
+            const uint4 w1 = pairs[2 * static_cast<size_t>(order[h]) + 1];
+            if ((w1.z & kLeafFlag) == 0)
+                order.push_back(w1.z);
+            if ((w1.w & kLeafFlag) == 0)
+                order.push_back(w1.w);
+        }
+        for (uint32_t k = 0; k < order.size(); k++)
+            newIndex[order[k]] = k;
+        std::vector<uint4> sorted(pairs.size());
+        for (uint32_t k = 0; k < order.size(); k++) {
+            uint4 w0 = pairs[2 * static_cast<size_t>(order[k])], w1 = pairs[2 * static_cast<size_t>(order[k]) + 1];
+            if ((w1.z & kLeafFlag) == 0)
+                w1.z = newIndex[w1.z];
+            if ((w1.w & kLeafFlag) == 0)
+                w1.w = newIndex[w1.w];
+            sorted[2 * static_cast<size_t>(k)] = w0, sorted[2 * static_cast<size_t>(k) + 1] = w1;
+        }
+        pairs.swap(sorted);
+        rootRef = 0;
+    }
+    return true;
+}
 
 struct HostBuilder {
     const rt_primitive* in;
@@ -490,39 +701,16 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
         return static_cast<uint32_t>(pairIndex[child]);
     };
 
-    // Quantisation grid: 65535 cells per axis across the root box.  A plane q stands
-    // for the real number gridMin + q * gridCell (both floats); lower planes round
-    // down, upper planes round up, checked in double so the quantised box contains
-    // the float box whatever the rounding of the division did.
     const rt_node& rootNode = nodes[0];
-    float gridMin[3], gridCell[3];
+    QuantGrid grid;
     for (int a = 0; a < 3; a++) {
-        gridMin[a] = rootNode.lower[a];
+        grid.gridMin[a] = rootNode.lower[a];
         const double ext = static_cast<double>(rootNode.upper[a]) - static_cast<double>(rootNode.lower[a]);
-        gridCell[a] = (ext > 0.0 && std::isfinite(ext)) ? static_cast<float>(ext / 65535.0) : 0.0f;
+        grid.gridCell[a] = (ext > 0.0 && std::isfinite(ext)) ? static_cast<float>(ext / 65535.0) : 0.0f;
     }
-    auto quantLo = [&](float v, int a) -> uint32_t {
-        if (!(gridCell[a] > 0.0f))
-            return 0u;
-        double q = std::floor((static_cast<double>(v) - gridMin[a]) / gridCell[a]);
-        q = std::min(65535.0, std::max(0.0, q));
-        while (q > 0.0 && static_cast<double>(gridMin[a]) + q * gridCell[a] > static_cast<double>(v))
-            q -= 1.0;
-        return static_cast<uint32_t>(q);
-    };
-    auto quantHi = [&](float v, int a) -> uint32_t {
-        if (!(gridCell[a] > 0.0f))
-            return 65535u; // flat or empty axis: A = 0, every plane sits at gridMin
-        double q = std::ceil((static_cast<double>(v) - gridMin[a]) / gridCell[a]);
-        q = std::min(65535.0, std::max(0.0, q));
-        while (q < 65535.0 && static_cast<double>(gridMin[a]) + q * gridCell[a] < static_cast<double>(v))
-            q += 1.0;
-        return static_cast<uint32_t>(q);
-    };
-    auto packBox = [&](const float* lo, const float* hi, uint32_t* w) {
-        for (int a = 0; a < 3; a++)
-            w[a] = quantLo(lo[a], a) | (quantHi(hi[a], a) << 16);
-    };
+    const float* gridMin = grid.gridMin;
+    const float* gridCell = grid.gridCell;
+    auto packBox = [&](const float* lo, const float* hi, uint32_t* w) { grid.packBox(lo, hi, w); };
     std::vector<uint4> pairs;
     uint32_t rootRef = 0;
     bool ownTree = false;
@@ -537,15 +725,11 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
         // attributes agree.)  The median
         // split of src/bvh.cpp:208-223 leaves heavily overlapping boxes, and a leaf of four
         // primitives makes a ray that grazes its box test all four.
-        struct Leaf {
-            float lo[3], hi[3], c[3];
-            uint32_t ref, count;
-        };
-        std::vector<Leaf> leaves;
+        std::vector<TreeLeaf> leaves;
         for (uint32_t i = 0; i < n_nodes; i++) {
             if (!seen[i] || !(nodes[i].data[0] & RT_LEAF_BIT))
                 continue;
-            Leaf l;
+            TreeLeaf l;
             for (int a = 0; a < 3; a++) {
                 l.lo[a] = nodes[i].lower[a], l.hi[a] = nodes[i].upper[a];
                 l.c[a] = 0.5f * (l.lo[a] + l.hi[a]);
@@ -556,7 +740,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
                 const uint32_t first = nodes[i].data[0] & ~RT_LEAF_BIT;
                 for (uint32_t k = 0; k < nodes[i].data[1]; k++) {
                     const rt_primitive& q = prims[first + k];
-                    Leaf t;
+                    TreeLeaf t;
                     for (int a = 0; a < 3; a++) {
                         t.lo[a] = std::min(q.v0.position[a], std::min(q.v1.position[a], q.v2.position[a]));
                         t.hi[a] = std::max(q.v0.position[a], std::max(q.v1.position[a], q.v2.position[a]));
@@ -570,162 +754,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
             }
             leaves.push_back(l);
         }
-        // Full-sweep SAH build in O(n log n): the leaves are sorted by centre once per axis; a
-        // node owns the same range [b, e) of all three orders, sweeps each for the cheapest split,
-        // and hands its halves down by a stable partition of the other two orders.
-        struct Build {
-            std::vector<Leaf>& L;
-            std::vector<uint4>& pairs;
-            std::vector<uint32_t> order[3], tmp, suffixCount;
-            std::vector<uint8_t> goesLeft;
-            std::vector<float> rightArea;
-            uint32_t maxDepth = 0;
-            decltype(packBox)& pack;
-            static float area(const float* lo, const float* hi)
-            {
-                const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
-                return 2.0f * (x * y + x * z + y * z);
-            }
-            void bounds(uint32_t b, uint32_t e, float* lo, float* hi) const
-            {
-                const std::vector<uint32_t>& idx = order[0];
-                for (int a = 0; a < 3; a++)
-                    lo[a] = L[idx[b]].lo[a], hi[a] = L[idx[b]].hi[a];
-                for (uint32_t i = b + 1; i < e; i++)
-                    for (int a = 0; a < 3; a++) {
-                        lo[a] = std::min(lo[a], L[idx[i]].lo[a]);
-                        hi[a] = std::max(hi[a], L[idx[i]].hi[a]);
-                    }
-            }
-            void start()
-            {
-                const uint32_t n = static_cast<uint32_t>(L.size());
-                for (int axis = 0; axis < 3; axis++) {
-                    order[axis].resize(n);
-                    for (uint32_t i = 0; i < n; i++)
-                        order[axis][i] = i;
-                    std::sort(order[axis].begin(), order[axis].end(), [&](uint32_t x, uint32_t y) {
-                        return L[x].c[axis] < L[y].c[axis] || (L[x].c[axis] == L[y].c[axis] && x < y);
-                    });
-                }
-                goesLeft.assign(n, 0);
-                tmp.resize(n);
-                rightArea.resize(n);
-                suffixCount.resize(n + 1);
-            }
-            // returns the child reference of the subtree over the range [b, e) of the three orders
-            uint32_t build(uint32_t b, uint32_t e, uint32_t depth)
-            {
-                maxDepth = std::max(maxDepth, depth);
-                if (e - b == 1)
-                    return L[order[0][b]].ref;
-                const uint32_t n = e - b;
-                float bestCost = std::numeric_limits<float>::infinity();
-                int bestAxis = -1;
-                uint32_t bestSplit = 0;
-                for (int axis = 0; axis < 3; axis++) {
-                    const uint32_t* idx = order[axis].data() + b;
-                    float lo[3], hi[3];
-                    uint32_t cnt = 0;
-                    suffixCount[n] = 0;
-                    for (uint32_t i = n; i-- > 0;) { // suffix boxes and primitive counts
-                        const Leaf& q = L[idx[i]];
-                        suffixCount[i] = suffixCount[i + 1] + q.count;
-                        if (i == n - 1)
-                            for (int a = 0; a < 3; a++)
-                                lo[a] = q.lo[a], hi[a] = q.hi[a];
-                        else
-                            for (int a = 0; a < 3; a++)
-                                lo[a] = std::min(lo[a], q.lo[a]), hi[a] = std::max(hi[a], q.hi[a]);
-                        rightArea[i] = area(lo, hi);
-                    }
-                    for (uint32_t i = 0; i + 1 < n; i++) { // split after element i
-                        const Leaf& q = L[idx[i]];
-                        if (i == 0)
-                            for (int a = 0; a < 3; a++)
-                                lo[a] = q.lo[a], hi[a] = q.hi[a];
-                        else
-                            for (int a = 0; a < 3; a++)
-                                lo[a] = std::min(lo[a], q.lo[a]), hi[a] = std::max(hi[a], q.hi[a]);
-                        cnt += q.count;
-                        const float cost = area(lo, hi) * (float)std::max(1u, cnt) + rightArea[i + 1] * (float)std::max(1u, suffixCount[i + 1]);
-                        if (cost < bestCost)
-                            bestCost = cost, bestAxis = axis, bestSplit = i + 1;
-                    }
-                }
-                // keep the depth bounded: fall back to the middle once a branch runs deep
-                if (bestAxis < 0 || depth + 2 + (uint32_t)std::ceil(std::log2((double)n)) > (uint32_t)kMaxStack) {
-                    bestAxis = 0;
-                    bestSplit = n / 2;
-                }
-                const uint32_t mid = b + bestSplit;
-                for (uint32_t i = b; i < e; i++)
-                    goesLeft[order[bestAxis][i]] = i < mid;
-                for (int axis = 0; axis < 3; axis++) {
-                    if (axis == bestAxis)
-                        continue;
-                    uint32_t* idx = order[axis].data();
-                    uint32_t nl = b, nr = 0;
-                    for (uint32_t i = b; i < e; i++) {
-                        if (goesLeft[idx[i]])
-                            idx[nl++] = idx[i];
-                        else
-                            tmp[nr++] = idx[i];
-                    }
-                    std::copy(tmp.begin(), tmp.begin() + nr, idx + nl);
-                }
-                const size_t me = pairs.size();
-                pairs.resize(me + 2);
-                float lo[3], hi[3];
-                uint32_t wl[3], wr[3];
-                bounds(b, mid, lo, hi);
-                pack(lo, hi, wl);
-                bounds(mid, e, lo, hi);
-                pack(lo, hi, wr);
-                const uint32_t rl = build(b, mid, depth + 1);
-                const uint32_t rr = build(mid, e, depth + 1);
-                pairs[me] = make_uint4(wl[0], wl[1], wl[2], wr[0]);
-                pairs[me + 1] = make_uint4(wr[1], wr[2], rl, rr);
-                return static_cast<uint32_t>(me / 2);
-            }
-        };
-        Build bld { leaves, pairs, {}, {}, {}, {}, {}, 0, packBox };
-        bld.start();
-        pairs.reserve(leaves.size() * 2);
-        rootRef = bld.build(0, static_cast<uint32_t>(leaves.size()), 1);
-        if (bld.maxDepth + 1 <= (uint32_t)kMaxStack) {
-            ownTree = true;
-            maxLevel = bld.maxDepth; // nodes on the longest path from the root to a leaf, as for the caller's tree
-            // breadth-first order: the records every ray starts with sit next to each other
-            if ((rootRef & kLeafFlag) == 0) {
-                const uint32_t nPairs = static_cast<uint32_t>(pairs.size() / 2);
-                std::vector<uint32_t> order, newIndex(nPairs, 0);
-                order.reserve(nPairs);
-                order.push_back(rootRef);
-                for (size_t h = 0; h < order.size(); h++) {
-                    const uint4 w1 = pairs[2 * static_cast<size_t>(order[h]) + 1];
-                    if ((w1.z & kLeafFlag) == 0)
-                        order.push_back(w1.z);
-                    if ((w1.w & kLeafFlag) == 0)
-                        order.push_back(w1.w);
-                }
-                for (uint32_t k = 0; k < order.size(); k++)
-                    newIndex[order[k]] = k;
-                std::vector<uint4> sorted(pairs.size());
-                for (uint32_t k = 0; k < order.size(); k++) {
-                    uint4 w0 = pairs[2 * static_cast<size_t>(order[k])], w1 = pairs[2 * static_cast<size_t>(order[k]) + 1];
-                    if ((w1.z & kLeafFlag) == 0)
-                        w1.z = newIndex[w1.z];
-                    if ((w1.w & kLeafFlag) == 0)
-                        w1.w = newIndex[w1.w];
-                    sorted[2 * static_cast<size_t>(k)] = w0, sorted[2 * static_cast<size_t>(k) + 1] = w1;
-                }
-                pairs.swap(sorted);
-                rootRef = 0;
-            }
-        } else {
-            pairs.clear();
-        }
+        ownTree = buildOwnTree(leaves, grid, pairs, rootRef, maxLevel);
     }
     if (!ownTree) {
         if (callerLevels > (uint32_t)kMaxStack)
