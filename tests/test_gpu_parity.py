@@ -118,6 +118,30 @@ CONFIGS = {
 }
 
 
+def test_three_kinds_of_light_odd_counts(ctx):
+    """Point, segment and parallelogram light in one scene, three shadow samples, three camera rays
+    per pixel (jittered 2x2 would be four: uniform sampling): sample slots and draws per hit that are
+    no multiple of anything the kernels treat specially, hits of mirror chains included."""
+    import copy
+    scn = copy.deepcopy(common.scene("CornellBox"))
+    scn.lights = [sio.point_light((0.0, 0.58, 0.0), (0.6, 0.6, 0.6)),
+                  sio.segment_light((-0.3, 0.5, 0.3), (0.3, 0.5, -0.3), (0.9, 0.2, 0.2), (0.2, 0.2, 0.9)),
+                  sio.parallelogram_light((-0.2, 0.56, -0.2), (0.4, 0.0, 0.0), (0.0, 0.0, 0.4), (1, 1, 1), (1, 0.5, 0.5), (0.5, 1, 0.5), (0.5, 0.5, 1))]
+    osc = _both(ctx, scn)
+    w, h = 83, 61
+    cam = sio.default_camera(w, h)
+    for shadows in (1, 0):
+        f = common.features(enableShading=1, enableShadows=shadows, enableReflections=1, shadingModel=1, numPixelSamples=3,
+                            numShadowSamples=3, maxRayDepth=3)
+        ref, st_o = osc.render(f, cam, w, h)
+        ctx.set_features(f)
+        img, st_g = ctx.render(cam, w, h)
+        maxabs, rmse = common.image_error(img, ref)
+        print(f"three lights, shadows {shadows}: rays {st_g['rays']} maxabs {maxabs:.3g}")
+        assert st_g["rays"] == st_o["rays"] and ref.any()
+        assert maxabs <= 2e-5 and rmse <= 2e-6
+
+
 @pytest.mark.parametrize("key", list(CONFIGS))
 def test_render_matches_oracle(ctx, key):
     name, fkw, w, h = CONFIGS[key]
