@@ -142,6 +142,37 @@ def test_three_kinds_of_light_odd_counts(ctx):
         assert maxabs <= 2e-5 and rmse <= 2e-6
 
 
+def test_jittered_sampling_and_glossy_reflections(ctx):
+    """generatePixelRaysStratified (src/render.cpp:103-131) on the queue-based path, and glossy
+    reflections (src/extra.cpp:329-368), whose sample directions consume draws in the recursion's
+    own order and therefore run on the per-pixel kernel, also combined with transparency and
+    depth of field."""
+    import copy
+    scn = copy.deepcopy(common.scene("CornellBox"))
+    scn.lights = [sio.cornell_parallelogram_light()]
+    scn.meshes[5].material["transparency"] = 0.5
+    osc = _both(ctx, scn)
+    w, h = 72, 56
+    cam = sio.default_camera(w, h)
+    cases = {
+        "jitter 2x2": dict(numPixelSamples=4, enableJitteredSampling=1, numShadowSamples=2),
+        "jitter, 7 samples asked": dict(numPixelSamples=7, enableJitteredSampling=1, numShadowSamples=1),
+        "glossy": dict(enableGlossyReflection=1, numGlossySamples=3, glossyExponent=0.5, maxRayDepth=2, numShadowSamples=2),
+        "glossy + transparency + lens": dict(enableGlossyReflection=1, numGlossySamples=2, glossyExponent=1.0, maxRayDepth=2, numShadowSamples=1,
+                                             enableTransparency=1, enableDepthOfField=1, numDepthOfFieldSamples=2, depthOfFieldDistance=2.5,
+                                             numPixelSamples=2),
+    }
+    for name, kw in cases.items():
+        f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, **kw)
+        ref, st_o = osc.render(f, cam, w, h)
+        ctx.set_features(f)
+        img, st_g = ctx.render(cam, w, h)
+        maxabs, rmse = common.image_error(img, ref)
+        print(f"{name}: rays {st_g['rays']} (oracle {st_o['rays']}) maxabs {maxabs:.3g}")
+        assert st_g["rays"] == st_o["rays"] and ref.any()
+        assert maxabs <= 2e-5 and rmse <= 2e-6
+
+
 @pytest.mark.parametrize("key", list(CONFIGS))
 def test_render_matches_oracle(ctx, key):
     name, fkw, w, h = CONFIGS[key]
