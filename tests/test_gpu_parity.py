@@ -173,6 +173,25 @@ def test_jittered_sampling_and_glossy_reflections(ctx):
         assert maxabs <= 2e-5 and rmse <= 2e-6
 
 
+def test_shading_models_and_texture_filters(ctx):
+    """Every ShadingModel (src/shading.cpp:30-153: Lambertian, Phong, Blinn-Phong, linear gradient)
+    and both texture filters (src/texture.cpp:13-71) on the textured cube with interpolated normals."""
+    scn = common.scene("CubeTextured", env_map=True)
+    osc = _both(ctx, scn)
+    w, h = 80, 60
+    cam = sio.default_camera(w, h)
+    for model in (0, 1, 2, 3):
+        for bilinear in (0, 1):
+            f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=model, enableNormalInterp=1,
+                                enableTextureMapping=1, enableBilinearTextureFiltering=bilinear, enableEnvironmentMap=model % 2)
+            ref, st_o = osc.render(f, cam, w, h)
+            ctx.set_features(f)
+            img, st_g = ctx.render(cam, w, h)
+            maxabs, rmse = common.image_error(img, ref)
+            assert st_g["rays"] == st_o["rays"] and ref.any(), (model, bilinear)
+            assert maxabs <= 2e-5 and rmse <= 2e-6, (model, bilinear, maxabs)
+
+
 @pytest.mark.parametrize("key", list(CONFIGS))
 def test_render_matches_oracle(ctx, key):
     name, fkw, w, h = CONFIGS[key]
