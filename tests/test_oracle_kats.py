@@ -1,6 +1,6 @@
 """The CPU oracle against every known-answer value the reference's own tests
 hold for this path, plus the two whole-frame figures recorded from the
-reference build.  No GPU involved."""
+reference build when the reference was surveyed.  No GPU involved."""
 import itertools
 
 import numpy as np
@@ -216,7 +216,7 @@ def test_sampler_stream():
 
 # ---- whole frames recorded from the reference build itself
 def test_cornell_pixel_sum_of_the_reference_build():
-    """Cornell box 128x128, shading (Blinn-Phong) + shadows +
+    """Recorded from a build of the reference: Cornell box 128x128, shading (Blinn-Phong) + shadows +
     reflections + BVH, 1 spp, default camera: sum of all pixels = 2570.015468."""
     osc = orc.OracleScene(common.scene("CornellBox"))
     f = common.features(enableShading=1, enableReflections=1, enableShadows=1, shadingModel=2)
@@ -225,7 +225,7 @@ def test_cornell_pixel_sum_of_the_reference_build():
 
 
 def test_teapot_ray_count_of_the_reference_build():
-    """teapot 960x540, same features: 596 998 intersect calls."""
+    """Recorded from a build of the reference: teapot 960x540, same features: 596 998 intersect calls."""
     osc = orc.OracleScene(common.scene("Teapot"))
     f = common.features(enableShading=1, enableReflections=1, enableShadows=1, shadingModel=2)
     _, st = osc.render(f, sio.default_camera(960, 540), 960, 540)
