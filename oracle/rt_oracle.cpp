@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #ifdef _OPENMP
@@ -134,6 +136,7 @@ struct State {
     Sampler sampler;
     orc_stats stats {};
     int policy = 0;
+    FILE* dump = nullptr; // debugging aid: every intersect call of one pixel (ORC_DUMP_PIXEL / ORC_DUMP_FILE)
 };
 
 // ---------------------------------------------------------------- intersect primitives
@@ -535,6 +538,7 @@ bool intersectRayWithBVHWhenEnabledAccel(State& st, Ray& ray, HitInfo& hitInfo)
 bool intersect(State& st, Ray& ray, HitInfo& hitInfo)
 {
     st.stats.rays++;
+    const Ray in = ray;
     bool isHit = false;
     if (st.f.enableAccelStructure) {
         isHit |= intersectRayWithBVHWhenEnabledAccel(st, ray, hitInfo);
@@ -544,6 +548,11 @@ bool intersect(State& st, Ray& ray, HitInfo& hitInfo)
     }
     for (size_t i = 0; i < st.scene.spheres.size(); i++)
         isHit |= intersectRayWithSphere(st.scene.spheres[i], ray, hitInfo, static_cast<int>(st.scene.materials.size() + i));
+    if (st.dump) { // origin, direction, t before, t after as bit patterns; hit flag; primitive
+        auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+        std::fprintf(st.dump, "%08x %08x %08x %08x %08x %08x %08x %08x %d %d\n", bits(in.origin.x), bits(in.origin.y), bits(in.origin.z),
+            bits(in.direction.x), bits(in.direction.y), bits(in.direction.z), bits(in.t), bits(ray.t), isHit ? 1 : 0, isHit ? hitInfo.prim : -1);
+    }
     return isHit;
 }
 
@@ -1216,6 +1225,13 @@ int orc_render(const orc_scene* scene, const orc_features* features, const orc_c
         return -1;
     const Camera cam(*camera);
     orc_stats total {};
+    // debugging aid: ORC_DUMP_PIXEL="x y" ORC_DUMP_FILE=path writes every intersect call of that pixel
+    FILE* dumpFile = nullptr;
+    int dumpX = -1, dumpY = -1;
+    if (const char* px = std::getenv("ORC_DUMP_PIXEL"))
+        if (const char* path = std::getenv("ORC_DUMP_FILE"))
+            if (std::sscanf(px, "%d %d", &dumpX, &dumpY) == 2)
+                dumpFile = std::fopen(path, "w");
 #ifdef _OPENMP
     const int nthreads = threads > 0 ? threads : omp_get_max_threads();
 #else
@@ -1230,6 +1246,8 @@ int orc_render(const orc_scene* scene, const orc_features* features, const orc_c
             for (int x = 0; x != width; x++) {
                 State st { *scene, *features, Sampler { static_cast<uint32_t>(height * x + y) } };
                 st.policy = policy;
+                if (dumpFile && x == dumpX && y == dumpY)
+                    st.dump = dumpFile;
                 const std::vector<Ray> rays = features->enableDepthOfField
                     ? generatePixelRaysForDepthOfField(st, cam, x, y, width, height)
                     : generatePixelRays(st, cam, x, y, width, height);
@@ -1244,6 +1262,8 @@ int orc_render(const orc_scene* scene, const orc_features* features, const orc_c
     }
     if (stats)
         *stats = total;
+    if (dumpFile)
+        std::fclose(dumpFile);
     return orc_bloom(features, out_rgb, width, height); // src/render.cpp:48-50
 }
 

@@ -85,6 +85,7 @@ struct rt_ctx {
     float* dBloom = nullptr; // thresholded copy of the frame for the bloom pass
     size_t bloomCap = 0;     // floats
     uint4* dPairs = nullptr;
+    uint4* dRefNodes = nullptr; // the caller's nodes as they came (replay of the reference's order of tests)
     uint32_t numPairs = 0; // pair records in dPairs
     float4* dTris = nullptr;
     float4* dAttrs = nullptr;
@@ -246,7 +247,7 @@ void rt_ctx_destroy(rt_ctx* ctx)
         return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = { ctx->dPairs, ctx->dTris, ctx->dAttrs, ctx->dMats, ctx->dTexs, ctx->dTexels, ctx->dSpheres, ctx->dLights,
+    void* ptrs[] = { ctx->dPairs, ctx->dRefNodes, ctx->dTris, ctx->dAttrs, ctx->dMats, ctx->dTexs, ctx->dTexels, ctx->dSpheres, ctx->dLights,
         ctx->dCounters, ctx->dFrame, ctx->dBloom };
     for (void* p : ptrs)
         if (p)
@@ -846,6 +847,19 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
     HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, uploadVec(&ctx->dPairs, pairs));
     ctx->numPairs = static_cast<uint32_t>(pairs.size() / 2);
+    // The caller's nodes, verbatim: a ray that meets two primitives at exactly the same distance is
+    // replayed over them in the reference's order of tests, which decides the one it keeps.  The
+    // replay's stack holds at most one entry per level of the caller's tree.
+    static_assert(sizeof(rt_node) == 2 * sizeof(uint4), "rt_node is two 16-byte words");
+    const bool replayable = callerLevels <= static_cast<uint32_t>(kMaxStack);
+    {
+        std::vector<uint4> ref(replayable ? static_cast<size_t>(n_nodes) * 2 : 0);
+        if (replayable)
+            std::memcpy(ref.data(), nodes, static_cast<size_t>(n_nodes) * sizeof(rt_node));
+        HIP_TRY(ctx, uploadVec(&ctx->dRefNodes, ref));
+    }
+    if (replayable)
+        maxLevel = std::max(maxLevel, callerLevels);
     HIP_TRY(ctx, uploadVec(&ctx->dTris, tris));
     HIP_TRY(ctx, uploadVec(&ctx->dAttrs, attrs));
     HIP_TRY(ctx, uploadVec(&ctx->dMats, mats));
@@ -874,6 +888,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
     std::memcpy(s.gridCell, gridCell, 12);
     s.nPrims = n_prims;
     s.tieByIndex = (ownTree && ctx->treeMode == 2) ? 1 : 0;
+    s.refNodes = replayable ? ctx->dRefNodes : nullptr;
     s.nMeshes = static_cast<int32_t>(n_meshes);
     s.nSpheres = static_cast<int32_t>(n_spheres);
     s.nTex = static_cast<int32_t>(n_images);

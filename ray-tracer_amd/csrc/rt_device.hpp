@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 #include "rt_fastdiv.hpp"
+#include "rt_trig.hpp"
 #include <stdint.h>
 
 #include "../../include/rt_amd.h"
@@ -135,6 +136,10 @@ struct DevScene {
     int32_t nMeshes, nSpheres, nLights, nTex;
     int32_t env[6];
     int32_t tieByIndex; // equal-t hits: the higher primitive index wins, whatever the order of the tests
+    // The caller's own nodes as they came (src/bvh_interface.h:28-54, two 16-B words each: lower,
+    // upper, data[2]); only read when a ray has to be replayed in the reference's order of tests
+    // (Tracer::settleTie).  Null when the caller's tree is deeper than a lane's stack.
+    const uint4* refNodes;
 };
 
 struct DevCamera {
@@ -493,6 +498,42 @@ __device__ __forceinline__ bool boxTest(f3 lo, f3 hi, f3 o, f3 inv, float tmax, 
     const float tOut = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kPadHi;
     entry = tIn;
     return tIn <= tOut && tIn <= tmax;
+}
+
+
+// intersectRayWithShape(AxisAlignedBox) the way the reference computes it (src/intersect.h:16;
+// body only in the prebuilt archive): slabs by true division, a zero direction component
+// leaves its slab out, an origin inside the box reports the distance to the exit.  Neither
+// conservative nor used for culling here: it exists to replay the reference's order of tests
+// (Tracer::settleTie).  `t` comes in as the limit and goes out as the reported distance.
+__device__ __forceinline__ bool refBoxTest(const float lo[3], const float hi[3], const float o[3], const float d[3], float& t)
+{
+    float tIn = 0.0f, tOut = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float tLo, tHi;
+        if (d[a] == 0.0f) {
+            tHi = 3.402823466e+38f;
+            tLo = 1.17549435e-38f;
+        } else {
+            tLo = (lo[a] - o[a]) / d[a];
+            tHi = (hi[a] - o[a]) / d[a];
+        }
+        const float mn = (tHi < tLo) ? tHi : tLo; // std::min(tLo, tHi)
+        const float mx = (tLo < tHi) ? tHi : tLo; // std::max(tLo, tHi)
+        tIn = (a == 0) ? mn : ((tIn < mn) ? mn : tIn);   // std::max(tIn, mn)
+        tOut = (a == 0) ? mx : ((mx < tOut) ? mx : tOut); // std::min(tOut, mx)
+    }
+    if (tIn < 0.0f) {
+        if (tOut <= 0.0f)
+            return false;
+        tIn = tOut;
+        tOut = 3.402823466e+38f;
+    }
+    if (tIn > tOut || tIn < 0.0f || tIn > t)
+        return false;
+    t = tIn;
+    return true;
 }
 
 } // namespace rt

@@ -213,8 +213,8 @@ struct Shader {
             const float sy = next1d(L.sMain);
             const float r = g.radius * sx;
             const float theta = kTwoPi * sy;
-            const f3 sU = g.u * r * cosf(theta);
-            const f3 sV = g.v * r * sinf(theta);
+            const f3 sU = g.u * r * cosLikeHost(theta);
+            const f3 sV = g.v * r * sinLikeHost(theta);
             const f3 dir = normalize(g.R + sU + sV);
             L.depth = fi + 1;
             launch(L, f.P + dir * 1.0e-5f, dir, kFltMax, K_RADIANCE);
@@ -347,6 +347,7 @@ struct Shader {
             case PH_TRACE:
                 if (L.r.active)
                     return;
+                tracer.settleTie(L.r);
                 if (sc.nSpheres)
                     tracer.spheres(L.r);
                 if (L.r.kind == K_RADIANCE) {
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(kBlockThreads) void intersectKernel(const DevScene 
     tracer.run(L, (16 << 8) | (32 << 16)); // every ray to completion, default switch points
     if (i >= n)
         return;
+    tracer.settleTie(L);
     tracer.spheres(L);
     rt_hit h;
     h.hit = (L.hitPrim != kHitNone) ? 1 : 0;

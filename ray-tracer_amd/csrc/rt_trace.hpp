@@ -40,6 +40,7 @@ struct RayState {
     uint32_t li, le;  // next primitive of the parked leaf and its end, as indices into the float4 array (6 per primitive)
     LdsWords top;     // first free entry of this lane's traversal stack
     bool active;      // still inside the traversal loop
+    bool tie;         // two primitives were met at exactly the same distance: see Tracer::settleTie
     uint32_t nInner, nTris;
     uint32_t itInner, itLeaf, itRuns; // counting builds: loop iterations this lane sat through
     uint32_t topHits[3];              // counting builds: inner steps at pair records below 1024 / 2048 / 4096
@@ -49,6 +50,58 @@ struct RayState {
 __device__ __forceinline__ f3 rcp3(f3 d)
 {
     return { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z) };
+}
+
+// BVHInterface::intersect over the caller's nodes, test for test as src/bvh.cpp:245-316 runs it
+// (see Tracer::settleTie).  Out of line on purpose: it runs for one ray in millions and must not
+// weigh on the register budget of the loops that call it.  `stk` is the calling lane's column of
+// the LDS stack (entries `stride` words apart), empty by now; returns (closest t as bits, primitive or kHitNone).
+static __device__ __attribute__((noinline)) uint2 replayReference(const uint4* __restrict__ nodes, const float4* __restrict__ tris, LdsWords stk,
+    uint32_t stride, float ox, float oy, float oz, float dx, float dy, float dz, float tmax)
+{
+    const float o[3] = { ox, oy, oz }, d[3] = { dx, dy, dz };
+    const f3 O = { ox, oy, oz }, D = { dx, dy, dz };
+    int hitPrim = kHitNone;
+    auto box = [&](uint32_t node, float& t) {
+        const uint4 a = nodes[2u * node], b = nodes[2u * node + 1u];
+        const float lo[3] = { __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z) };
+        const float hi[3] = { __uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y) };
+        t = kFltMax;
+        return refBoxTest(lo, hi, o, d, t);
+    };
+    float tRoot;
+    if (!box(0u, tRoot))
+        return make_uint2(__float_as_uint(tmax), (uint32_t)kHitNone);
+    uint32_t depth = 0;
+    stk[0] = 0u;
+    depth = 1;
+    while (depth != 0u) {
+        const uint32_t node = stk[--depth * stride];
+        const uint4 w = nodes[2u * node + 1u];
+        if (w.z & RT_LEAF_BIT) {
+            const uint32_t first = w.z & ~RT_LEAF_BIT;
+            for (uint32_t i = first; i < first + w.w; i++) {
+                float t;
+                if (triangleTestLazy(tris + 6u * i, O, D, tmax, t)) {
+                    tmax = t;
+                    hitPrim = (int)i;
+                }
+            }
+            continue;
+        }
+        float tL, tR;
+        const bool hL = box(w.z, tL), hR = box(w.w, tR);
+        if (hL && hR) {
+            const bool leftFirst = tL < tR;
+            stk[depth++ * stride] = leftFirst ? w.w : w.z;
+            stk[depth++ * stride] = leftFirst ? w.z : w.w;
+        } else if (hL) {
+            stk[depth++ * stride] = w.z;
+        } else if (hR) {
+            stk[depth++ * stride] = w.w;
+        }
+    }
+    return make_uint2(__float_as_uint(tmax), (uint32_t)hitPrim);
 }
 
 template <bool STATS>
@@ -84,6 +137,7 @@ struct Tracer {
         r.cur = kRefNone;
         r.pend = 0u;
         r.active = false;
+        r.tie = false;
     }
 
     // The root box test of src/bvh.cpp:253-259: does the ray enter the scene's box at all?
@@ -291,9 +345,20 @@ struct Tracer {
             r.nTris++;
         // Of two primitives hit at exactly the same t the reference keeps the one it tests later
         // (t <= ray.t, src/bvh.cpp:272-279): inside a leaf that is the one with the higher index.
-        // A hierarchy of the library's own visits them in another order, so it decides by the index.
-        if (triangleTestLazy(sc.tris + r.li, r.o, r.d, r.tmax, t)
-            && !(sc.tieByIndex && t == r.tmax && r.hitPrim >= 0 && (int)(r.li / 6u) < r.hitPrim)) {
+        // A hierarchy of the library's own visits them in another order, so it decides by the index
+        // for the time being, and the ray is marked: which of the two the reference tests later depends on
+        // its own walk through the caller's tree, which settleTie() repeats once the traversal is over.
+        bool accept = triangleTestLazy(sc.tris + r.li, r.o, r.d, r.tmax, t);
+        if (accept && t == r.tmax && r.hitPrim >= 0) {
+            // (binary visibility asks for no primitive; a light sample under transparency looks at
+            // nothing but the material of what it meets)
+            if (r.kind == K_RADIANCE)
+                r.tie = true;
+            else if (r.kind == K_SHADOW_CLOSEST)
+                r.tie = r.tie || sc.attrs[4u * (r.li / 6u) + 3u].w != sc.attrs[4u * (uint32_t)r.hitPrim + 3u].w;
+            accept = !(sc.tieByIndex && (int)(r.li / 6u) < r.hitPrim);
+        }
+        if (accept) {
             r.tmax = t;
             r.hitPrim = (int)(r.li / 6u);
             // Binary visibility only asks whether the closest hit lies more
@@ -308,6 +373,24 @@ struct Tracer {
         r.li += 6u;
         if (r.li >= r.le)
             r.pend = 0u;
+    }
+
+    // Which of two primitives met at exactly the same t the reference keeps is a matter of its order
+    // of tests (it accepts t <= ray.t, src/bvh.cpp:272-279): the leaf it reaches later wins, and that
+    // order follows from its own box routine over the caller's nodes -- entry distances by true
+    // division, the exit distance for an origin inside a box, no culling by the closest hit
+    // (src/bvh.cpp:283-313).  Such ties come about once in some millions of rays (coplanar or
+    // edge-sharing primitives), so the marked ray is simply traced again the reference's way; the
+    // closest t is the same, the primitive is the reference's.  Call when the traversal has ended
+    // and before the spheres.
+    __device__ __forceinline__ void settleTie(RayState& r) const
+    {
+        if (__builtin_expect(r.tie, 0) && sc.refNodes != nullptr && accel) {
+            const uint2 res = replayReference(sc.refNodes, sc.tris, stk, stride, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.slen);
+            r.tmax = __uint_as_float(res.x);
+            r.hitPrim = (int)res.y;
+        }
+        r.tie = false;
     }
 
     // Spheres are tested after the BVH, in order, against the current ray.t
@@ -436,8 +519,8 @@ __device__ __forceinline__ void cameraRay(const DevCamera& cam, const DevFeat& f
         const float r1 = next1d(sLens);
         const float angle = r0 * kTwoPi;
         const float dist = sqrtf(r1) * (ft.dofDiameter * 0.5f);
-        const float ox = cosf(angle) * dist;
-        const float oy = sinf(angle) * dist;
+        const float ox = cosLikeHost(angle) * dist; // the C library's results, bit for bit (rt_trig.hpp)
+        const float oy = sinLikeHost(angle) * dist;
         o = cam.pos + ox * cam.up + oy * cam.left;
         d = normalize(pof - o);
     } else {

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
             }
             // ---- paths whose ray has finished: record the hit, go on with a child ray or retire
             while (have && !r.active) {
+                tracer.settleTie(r);
                 if (sc.nSpheres)
                     tracer.spheres(r);
                 bool childLaunched = false;
@@ -650,8 +651,11 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
 #else
 #define RT_SHADOW_ATTR
 #endif
+// (the variant that follows light through transparent surfaces needs a register or two more than six
+// waves per SIMD leave it; held to that budget it keeps them, at the price of a spill outside the loop)
+#define RT_SHADOW_TRANSP_ATTR(on) __attribute__((amdgpu_waves_per_eu((on) ? 6 : 1)))
 template <bool STATS, bool TRANSP>
-__global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+__global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR RT_SHADOW_TRANSP_ATTR(TRANSP && !STATS) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR void shadowTraceKerne
     r.cycInner = r.cycLeaf = r.cycRun = 0;
     const long long tKernel = STATS ? clock64() : 0;
     const long long tWall = STATS ? wall_clock64() : 0; // 100 MHz, the same on every XCD (the shader clock is not)
-    uint32_t item = 0, extra = 0;
+    uint32_t item = 0, extra = 0, extraThis = 0; // rays that went on through a surface: of this wave's lane, of its current sample
     bool have = false, dead = false;
     WaveQueue q;
     q.start(total, wp.ownShare, wp.chunk, 64u);
@@ -690,8 +694,20 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR void shadowTraceKerne
                 if (TRANSP) {
                     curKd = ld3(wb.nodeB[fastDiv(item, wp.divSlots)].mkd); // src/light.cpp:126
                     tprod = 1.0f;
+                    extraThis = 0;
                 }
             }
+        }
+        if (TRANSP && have && !r.active && r.tie) {
+                // Two materials met at exactly the same distance: which of them the reference keeps takes
+                // its own walk through the caller's tree (Tracer::settleTie).  Not here, where a call would
+                // weigh on every ray: the sample is left to the shading kernel, which follows it again that way.
+                r.tie = false;
+                if (sc.refNodes != nullptr && ft.accel) {
+                    wb.svis[item] = 2;
+                    extra -= extraThis;
+                    have = false;
+                }
         }
         if (have && !r.active) {
             if (sc.nSpheres)
@@ -723,6 +739,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR void shadowTraceKerne
                     const f3 d = r.d;
                     tracer.launch(r, hp + d * 1.0e-5f, d, kFltMax, K_SHADOW_CLOSEST); // src/recursive.cpp:98-111
                     extra++;
+                    extraThis++;
                 } else {
                     float4* sr = wb.srays + 3u * (size_t)item;
                     if (atPoint) {
@@ -777,12 +794,73 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR void shadowTraceKerne
     }
 }
 
-__global__ __launch_bounds__(256) void shadowShadeKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
-    const DevCounters* __restrict__ ctr)
+// A light sample under transparency the traversal kernel left undone (two materials met at exactly
+// the same distance): testVisibilityLightSampleTransparency (src/light.cpp:112-151) once more, every
+// intersect call replayed in the reference's own order of tests.  Leaves the tinted light and the
+// visibility flag where the traversal kernel would have, and counts the rays that went on through a surface.
+__device__ __attribute__((noinline)) void redoTransparentSample(const DevScene& sc, const WfParams& wp, const WfBuffers& wb, DevCounters* ctr,
+    uint32_t item, LdsWords stk, uint32_t stride)
 {
+    float4* sr = wb.srays + 3u * (size_t)item;
+    const float4 a = sr[0], b = sr[1];
+    const uint32_t node = fastDiv(item, wp.divSlots);
+    const float4 a0 = wb.nodeA[4u * (size_t)node];
+    const f3 P = { a0.x, a0.y, a0.z };
+    f3 o = { a.x, a.y, a.z };
+    const f3 d = { b.x, b.y, b.z };
+    float tmax = a.w;
+    f3 curKd = ld3(wb.nodeB[node].mkd); // src/light.cpp:126
+    float tprod = 1.0f;
+    unsigned long long extra = 0;
+    for (;;) {
+        const uint2 res = replayReference(sc.refNodes, sc.tris, stk, stride, o.x, o.y, o.z, d.x, d.y, d.z, tmax);
+        float t = __uint_as_float(res.x);
+        int prim = (int)res.y;
+        for (int k = 0; k < sc.nSpheres; k++) { // src/bvh.cpp:354-355
+            float ts;
+            if (sphereTest(sc.spheres[k], o, d, t, ts)) {
+                t = ts;
+                prim = -2 - k;
+            }
+        }
+        const f3 hp = o + t * d;
+        const bool atPoint = allEpsEq(hp, P, 0.0001f);
+        if (prim != kHitNone && !atPoint) { // src/light.cpp:138-150
+            const DevMaterial hm = prim >= 0 ? sc.mats[__float_as_uint(sc.attrs[4u * (uint32_t)prim + 3u].w)] : sc.mats[sc.spheres[-2 - prim].material];
+            if (hm.transparency != 1.0f) {
+                curKd = ld3(hm.kd);
+                tprod *= hm.transparency;
+                o = hp + d * 1.0e-5f; // src/recursive.cpp:98-111
+                tmax = kFltMax;
+                extra++;
+                continue;
+            }
+        }
+        if (atPoint) {
+            const float4 c = sr[2];
+            const f3 v = mk3(c.x, c.y, c.z) * curKd * tprod;
+            sr[2] = make_float4(v.x, v.y, v.z, 0.0f);
+            wb.svis[item] = 1;
+        } else {
+            wb.svis[item] = 0;
+        }
+        break;
+    }
+    if (extra) {
+        atomicAdd(&ctr->rays, extra);
+        atomicAdd(&ctr->sRays, extra);
+    }
+}
+
+__global__ __launch_bounds__(256) void shadowShadeKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+    DevCounters* __restrict__ ctr)
+{
+    __shared__ uint32_t redoStack[kMaxStack * 256]; // only for redoTransparentSample: a column of kMaxStack entries per lane
     const uint32_t nNodes = ctr->nodes.v < wb.maxNodes ? ctr->nodes.v : wb.maxNodes;
     const uint32_t total = nNodes * wp.slots;
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+        if (wb.svis[item] == 2)
+            redoTransparentSample(sc, wp, wb, ctr, item, (LdsWords)(redoStack + threadIdx.x), 256u);
         f3 c = { 0.0f, 0.0f, 0.0f };
         const float4* sr = wb.srays + 3u * (size_t)item;
         const float4 col = sr[2];

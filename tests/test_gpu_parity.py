@@ -216,6 +216,91 @@ def test_render_matches_oracle(ctx, key):
     assert maxabs <= 2e-5 and rmse <= 2e-6
 
 
+def test_hundreds_of_camera_rays_per_pixel():
+    """The sample counts of the largest configuration (64 pixel samples x 5 lens samples = 320 camera
+    rays per pixel, area light x 4, transparency) and an odd count beyond 256 (17 x 17 = 289): a
+    pixel's rays then take more than one round of the kernel that adds them up, and their number is
+    no multiple of four.  Queue-based path against the oracle, and bit for bit against the per-pixel
+    kernel, which walks a pixel in the recursion's own order."""
+    scn = common.scene("Dragon")
+    scn.lights = [sio.cornell_parallelogram_light()]
+    scn.meshes[0].material["transparency"] = 0.6
+    import orc
+    osc = orc.OracleScene(scn)
+    w, h = 21, 13
+    cam = sio.default_camera(w, h, distance=1.6)
+    for spp, lens, shadow_samples in ((64, 5, 4), (17, 17, 1)):
+        f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, numPixelSamples=spp,
+                            numShadowSamples=shadow_samples, enableTransparency=1, enableDepthOfField=1,
+                            numDepthOfFieldSamples=lens, depthOfFieldDistance=2.5, maxRayDepth=2)
+        ref, st_o = osc.render(f, cam, w, h)
+        images = []
+        for env in (dict(RT_AMD_PER_PIXEL=0), dict(RT_AMD_PER_PIXEL=1)):
+            c = _ctx_with_env(**env)
+            c.upload_scene(scn)
+            c.set_features(f)
+            img, st = c.render(cam, w, h)
+            c.close()
+            assert st["rays"] == st_o["rays"], (spp, lens, env, st["rays"], st_o["rays"])
+            images.append(img)
+        maxabs, rmse = common.image_error(images[0], ref)
+        print(f"{spp} x {lens} camera rays per pixel: {st_o['rays']} rays, maxabs {maxabs:.3g} rmse {rmse:.3g}")
+        assert ref.any() and maxabs <= 2e-5 and rmse <= 2e-6
+        assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
+
+
+def test_primitives_met_at_the_same_distance():
+    """Every mesh of the Cornell box a second time, in place, under another material: whatever a ray
+    meets, it meets twice at exactly the same t, and the reference keeps the primitive it tests later
+    (t <= ray.t, src/bvh.cpp:272-279), which follows from its walk through its own tree.  The copies
+    differ in colour, mirror colour and transparency, so the wrong choice shows in ray counts and
+    pixels at once.  Every kernel that asks for a primitive (queue-based, per-pixel, batch
+    intersection; with and without transparency, whose light samples look at the material of what
+    they meet) under every traversal tree, and with the BVH off."""
+    import copy
+    scn = copy.deepcopy(common.scene("CornellBox", env_map=True))
+    twins = []
+    for i, m in enumerate(scn.meshes):
+        t = copy.deepcopy(m)
+        t.material["kd"] = (0.9 - 0.1 * (i % 5), 0.2 + 0.15 * (i % 4), 0.3 + 0.1 * (i % 6))
+        t.material["ks"] = (0.0, 0.0, 0.0) if i % 2 else (0.4, 0.5, 0.6)
+        t.material["transparency"] = 1.0 if i % 3 else 0.4
+        twins.append(t)
+    # interleaved and appended: some copies come before their originals in primitive order, some after
+    scn.meshes = twins[:3] + scn.meshes + twins[3:]
+    scn.lights = [sio.point_light((0.0, 0.58, 0.0), (1.0, 1.0, 1.0)), sio.cornell_parallelogram_light()]
+    import orc
+    osc = orc.OracleScene(scn)
+    w, h = 64, 48
+    cam = sio.default_camera(w, h)
+    rng = np.random.default_rng(5)
+    rays = np.zeros(4000, dtype=sio.RAY)
+    rays["origin"] = rng.uniform(-0.3, 0.3, (len(rays), 3))
+    d = rng.normal(size=(len(rays), 3))
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["t"] = np.finfo(np.float32).max
+    for transp, accel in ((0, 1), (1, 1), (1, 0)):
+        f = common.features(enableAccelStructure=accel, enableShading=1, enableShadows=1, enableReflections=1, enableTransparency=transp,
+                            enableEnvironmentMap=1, shadingModel=2, numPixelSamples=2, numShadowSamples=2, maxRayDepth=3)
+        ref, st_o = osc.render(f, cam, w, h)
+        r_o, h_o, _ = osc.intersect(f, rays)
+        for env in (dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=1, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=0, RT_AMD_PER_PIXEL=0),
+                    dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=1)):
+            c = _ctx_with_env(**env)
+            c.upload_scene(scn)
+            c.set_features(f)
+            img, st = c.render(cam, w, h)
+            r_g, h_g = c.intersect(rays)
+            c.close()
+            assert st["rays"] == st_o["rays"], (transp, accel, env, st["rays"], st_o["rays"])
+            maxabs, rmse = common.image_error(img, ref)
+            assert maxabs <= 2e-5 and rmse <= 2e-6, (transp, accel, env, maxabs)
+            assert np.array_equal(h_g["primitive"], h_o["primitive"]), (transp, accel, env)
+            assert np.array_equal(h_g["material"], h_o["material"])
+            assert np.array_equal(r_g["t"].view(np.uint32), r_o["t"].view(np.uint32))
+        assert h_o["hit"].mean() > 0.5 and ref.any()
+
+
 def test_transparency_tree_matches_oracle_and_per_pixel_kernel():
     """Every surface both mirroring and half transparent, depth cap 5: each camera ray grows the
     full binary tree of hits of src/recursive.cpp:43-63, and the light reaches every hit through

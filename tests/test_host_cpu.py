@@ -88,6 +88,17 @@ def test_fast_division_is_exact(tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("0 wrong"), out.stdout
 
 
+def test_device_sine_and_cosine_equal_the_c_librarys(tmp_path):
+    """The lens and glossy samples take the sine and cosine of an angle in [0, 2 pi]
+    (src/extra.cpp:27-44, :353-356).  The header the kernels use evaluates them the way the host's C
+    library does; compiled for the host it must give the library's bits for every float in that range."""
+    exe = str(tmp_path / "trig_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(common.ROOT, "tests", "cpp", "trig_check.cpp")],
+                   check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith(" 0 wrong"), out.stdout
+
+
 def test_shard_floats_matches_python_layout():
     for (w, h) in [(1920, 1080), (17, 9), (8, 8), (3840, 2160), (100, 1)]:
         for world in (1, 2, 3, 4, 8):

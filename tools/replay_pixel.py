@@ -1,0 +1,48 @@
+"""Every intersect call the oracle makes for one pixel of a frame (lens samples, transparency, mirror
+depth 2 on the dragon stand-in), replayed on the device ray by ray under two traversal trees: the
+way to find the one ray behind a pixel that differs.
+
+    python tools/replay_pixel.py [x y]
+"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import common, orc
+sio = importlib.import_module("ray-tracer_amd.scene_io")
+capi = importlib.import_module("ray-tracer_amd.capi")
+scn = common.scene("Dragon")
+scn.lights = [sio.cornell_parallelogram_light()]
+scn.meshes[0].material["transparency"] = 0.6
+osc = orc.OracleScene(scn)
+w, h = 21, 13
+cam = sio.default_camera(w, h, distance=1.6)
+f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, numPixelSamples=17, numShadowSamples=1,
+                    enableTransparency=1, enableDepthOfField=1, numDepthOfFieldSamples=17, depthOfFieldDistance=2.5, maxRayDepth=2)
+path = "/tmp/orc_dump.txt"
+px = sys.argv[1:3] if len(sys.argv) >= 3 else ["15", "11"]
+os.environ["ORC_DUMP_PIXEL"] = " ".join(px)
+os.environ["ORC_DUMP_FILE"] = path
+osc.render(f, cam, w, h, threads=1)
+rows = [l.split() for l in open(path)]
+bits = np.array([[int(v, 16) for v in r[:8]] for r in rows], dtype=np.uint32).view(np.float32)
+hit_o = np.array([int(r[8]) for r in rows]); prim_o = np.array([int(r[9]) for r in rows])
+rays = np.zeros(len(rows), dtype=sio.RAY)
+rays["origin"] = bits[:, 0:3]; rays["direction"] = bits[:, 3:6]; rays["t"] = bits[:, 6]
+print(len(rows), "intersect calls in the pixel")
+for tree in (2, 0):
+    os.environ["RT_AMD_TREE"] = str(tree)
+    c = capi.Context(0)
+    c.upload_scene(scn)
+    c.set_features(f)
+    r, hits = c.intersect(rays)
+    bad = np.nonzero((hits["hit"] != hit_o) | (hits["primitive"] != prim_o) | (r["t"].view(np.uint32) != bits[:, 7].view(np.uint32)))[0]
+    print("tree", tree, "differing calls:", len(bad))
+    for i in bad[:6]:
+        print(" call", i, "o", rays["origin"][i], "d", rays["direction"][i], "t in", rays["t"][i], "| oracle hit", hit_o[i], prim_o[i], bits[i, 7],
+              "| device hit", hits["hit"][i], hits["primitive"][i], r["t"][i])
+    # the oracle itself, called again ray by ray
+    r2, h2, _ = osc.intersect(f, rays)
+    bad2 = np.nonzero((h2["hit"] != hit_o) | (h2["primitive"] != prim_o))[0]
+    print(" oracle replay differing:", len(bad2))
+    c.close()
