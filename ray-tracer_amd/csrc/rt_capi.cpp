@@ -721,9 +721,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
         // caller's leaves with their primitive ranges and boxes as they are (mode 1).  Which
         // primitive a ray hits and its t do not depend on the hierarchy; only the number of boxes
         // and primitives a ray has to test does.  (Of two primitives hit at exactly the same t
-        // the reference keeps the one it tests later, and so does this traversal, but which one
-        // that is can differ; such pairs share an edge, and on it material and interpolated
-        // attributes agree.)  The median
+        // the reference keeps the one it tests later; a ray that meets such a pair is traced once
+        // more in the reference's own order over the caller's nodes, Tracer::settleTie.)  The median
         // split of src/bvh.cpp:208-223 leaves heavily overlapping boxes, and a leaf of four
         // primitives makes a ray that grazes its box test all four.
         std::vector<TreeLeaf> leaves;

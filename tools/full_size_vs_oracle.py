@@ -18,6 +18,9 @@ capi = importlib.import_module("ray-tracer_amd.capi")
 sio = importlib.import_module("ray-tracer_amd.scene_io")
 scene, features, w, h, desc = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "dragon")
 distance = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
+if len(sys.argv) > 4:  # a smaller frame of the same workload: width height
+    w, h = int(sys.argv[3]), int(sys.argv[4])
+    desc += f" [at {w}x{h}]"
 cam = sio.default_camera(w, h, distance=distance)
 print(f"== {desc}, camera distance {distance}", flush=True)
 t0 = time.time()
