@@ -194,9 +194,11 @@ int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_n
  * which primitives exist and in which order; the rays are walked through a
  * hierarchy of the library's own over those primitives (which primitive a ray
  * hits and its t do not depend on the hierarchy; of two primitives hit at
- * exactly the same t the one with the higher index is reported, as the
- * reference does inside a leaf).  generation (optional) receives a counter
- * that changes with every upload. */
+ * exactly the same t the reference reports the one it tests later, and so
+ * does the library: the nodes are also kept as they came, and such a ray is
+ * traced once more over them in the reference's order of tests,
+ * src/bvh.cpp:245-316).  generation (optional) receives a counter that
+ * changes with every upload. */
 int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const rt_primitive* prims,
                     uint32_t n_prims, const rt_material* mesh_materials, uint32_t n_meshes,
                     const rt_image* images, uint32_t n_images, const int32_t env_faces[6],
