@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include "rt_fastdiv.hpp"
 #include "rt_trig.hpp"
+#include "rt_pow.hpp"
 #include <stdint.h>
 
 #include "../../include/rt_amd.h"
@@ -387,7 +388,7 @@ __device__ __forceinline__ f3 computeShading(const DevFeat& ft, f3 N, f3 kd, f3 
     }
     if (d < 0.0f)
         return diffuse;
-    const f3 specular = lightColor * ks * powf(d, shininess);
+    const f3 specular = lightColor * ks * powLikeHost(d, shininess); // the C library's result, bit for bit (rt_pow.hpp)
     return diffuse + specular;
 }
 

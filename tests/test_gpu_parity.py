@@ -213,7 +213,11 @@ def test_render_matches_oracle(ctx, key):
     print(f"{key}: rays gpu {st_g['rays']} oracle {st_o['rays']} maxabs {maxabs:.3g} rmse {rmse:.3g} exact {exact:.4f} "
           f"kernel {st_g['kernel_ms']:.3f} ms")
     assert st_g["rays"] == st_o["rays"]
-    assert maxabs <= 2e-5 and rmse <= 2e-6
+    assert maxabs <= 2e-5 and rmse <= 2e-6  # the stated tolerance
+    # observed: every float of every frame equal to the oracle's, now that the kernels take sine, cosine
+    # and power the way the host's C library does (a library built without fused multiply-adds may round
+    # one power in 1e7 differently, hence no demand for all of them)
+    assert exact >= 0.999
 
 
 def test_hundreds_of_camera_rays_per_pixel():

@@ -99,6 +99,21 @@ def test_device_sine_and_cosine_equal_the_c_librarys(tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith(" 0 wrong"), out.stdout
 
 
+def test_device_power_function_equals_the_c_librarys(tmp_path):
+    """The specular terms raise a cosine to the shininess with the C library's powf
+    (src/shading.cpp:92-153).  The header the kernels use evaluates it the way glibc does; compiled for
+    the host it must give the library's bits: 2e8 pairs of cosines and shininess values plus the
+    special arguments.  (A C library built without fused multiply-adds rounds a few intermediate doubles
+    differently, some three results in 1e8: that many are let through.)"""
+    exe = str(tmp_path / "pow_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(common.ROOT, "tests", "cpp", "pow_check.cpp")],
+                   check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    total, wrong = (int(v) for v in out.stdout.strip().splitlines()[-1].replace(" pairs,", "").replace(" wrong", "").split())
+    assert total > 200000000 and wrong <= 20, out.stdout
+
+
 def test_shard_floats_matches_python_layout():
     for (w, h) in [(1920, 1080), (17, 9), (8, 8), (3840, 2160), (100, 1)]:
         for world in (1, 2, 3, 4, 8):
