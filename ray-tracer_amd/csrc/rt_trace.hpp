@@ -355,7 +355,7 @@ struct Tracer {
             if (r.kind == K_RADIANCE)
                 r.tie = true;
             else if (r.kind == K_SHADOW_CLOSEST)
-                r.tie = r.tie || sc.attrs[4u * (r.li / 6u) + 3u].w != sc.attrs[4u * (uint32_t)r.hitPrim + 3u].w;
+                r.tie = r.tie || __float_as_uint(sc.attrs[4u * (r.li / 6u) + 3u].w) != __float_as_uint(sc.attrs[4u * (uint32_t)r.hitPrim + 3u].w); // mesh ids
             accept = !(sc.tieByIndex && (int)(r.li / 6u) < r.hitPrim);
         }
         if (accept) {
