@@ -303,6 +303,24 @@ def test_primitives_met_at_the_same_distance():
             assert np.array_equal(h_g["material"], h_o["material"])
             assert np.array_equal(r_g["t"].view(np.uint32), r_o["t"].view(np.uint32))
         assert h_o["hit"].mean() > 0.5 and ref.any()
+    # the same over the tree of the reference's other builder (SAH + binning, src/extra.cpp:493-543): another
+    # order of tests, other primitives kept
+    nodes, prims, _, _ = capi.bvh_build(scn.primitives(), sah_binning=True)
+    osc = orc.OracleScene(scn, nodes, prims)
+    f = common.features(enableShading=1, enableShadows=1, enableReflections=1, enableTransparency=1, enableEnvironmentMap=1,
+                        shadingModel=2, numPixelSamples=2, numShadowSamples=2, maxRayDepth=3)
+    ref, st_o = osc.render(f, cam, w, h)
+    r_o, h_o, _ = osc.intersect(f, rays)
+    for env in (dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=0, RT_AMD_PER_PIXEL=1)):
+        c = _ctx_with_env(**env)
+        c.upload_scene(scn, nodes, prims)
+        c.set_features(f)
+        img, st = c.render(cam, w, h)
+        r_g, h_g = c.intersect(rays)
+        c.close()
+        assert st["rays"] == st_o["rays"], (env, st["rays"], st_o["rays"])
+        assert common.image_error(img, ref)[0] <= 2e-5
+        assert np.array_equal(h_g["primitive"], h_o["primitive"]) and np.array_equal(h_g["material"], h_o["material"])
 
 
 def test_transparency_tree_matches_oracle_and_per_pixel_kernel():
