@@ -1185,8 +1185,11 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         else if (mirrors || passes)
             nodesPerPath = static_cast<uint64_t>(F.maxRayDepth) + 1;
         const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * nodesPerPath;
+        // per light sample: its contribution (12 B) and its ray, 32 B; with transparency the ray record also
+        // carries the light's colour (48 B) and a visibility byte goes with it
+        const uint64_t perItem = transp ? (12ull + 48 + 1) : (12ull + 32);
         const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + 32 + (F.enableEnvironmentMap ? 12 : 0))
-            + nodesPerPixel * (64 + sizeof(NodeB) + (12ull + 48 + 1) * std::max(1u, slots));
+            + nodesPerPixel * (64 + sizeof(NodeB) + perItem * std::max(1u, slots));
         uint64_t batchSlots = ctx->workspaceCap / std::max<uint64_t>(1, bytesPerPixel);
         batchSlots = std::min<uint64_t>(batchSlots, 0x7fffffffull / wp.R);                                       // path index in 31 bits
         // item index (node * slots + slot) in 32 bits, with room for the queue head to run past the end
@@ -1202,7 +1205,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, slots);
         const size_t want[10] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
             F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
-            static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * 48, items, static_cast<size_t>(paths) * 32 };
+            static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * (transp ? 48 : 32), transp ? items : 16, static_cast<size_t>(paths) * 32 };
         for (int i = 0; i < 10; i++) {
             if (ctx->wsBytes[i] < want[i]) {
                 HIP_TRY(ctx, hipStreamSynchronize(stream));
