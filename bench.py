@@ -178,8 +178,8 @@ def main():
     if args.camera_distance != 3.0:
         desc += f" [camera distance {args.camera_distance} instead of the default 3.0]"
 
-    # three at N = 1 (a fourth context's worst-case workspace does not fit beside the others at the
-    # headline size); four on a shard, where they fit and the fixed part of a frame weighs more
+    # three at N = 1 (measured: four and five frames in flight are no faster at the headline size);
+    # four on a shard, where the fixed part of a frame weighs more
     lanes = args.in_flight if args.in_flight > 0 else (3 if world == 1 else 4)
     stride = capi.shard_floats(width, height, 0, world)
     ctxs, streams, frames, packeds, gathereds = [], [], [], [], []
