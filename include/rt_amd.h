@@ -27,7 +27,9 @@ enum rt_status {
     RT_ERR_INVALID = -1,     /* bad argument / malformed BVH */
     RT_ERR_UNSUPPORTED = -2, /* feature outside this path (motion blur, bloom sizes the reference cannot run) */
     RT_ERR_DEVICE = -3,      /* HIP runtime failure */
-    RT_ERR_STATE = -4        /* call order (render before scene upload, ...) */
+    RT_ERR_STATE = -4,       /* call order (render before scene upload, ...) */
+    RT_ERR_NOMEM = -5,       /* host memory ran out inside the library */
+    RT_ERR_INTERNAL = -6     /* any other failure inside the library's host code (no exception crosses the C ABI) */
 };
 
 /* Vertex, framework/include/framework/mesh.h:14-20 (32 B) */

@@ -16,6 +16,8 @@
 #include <limits>
 #include <string>
 #include <memory>
+#include <new>
+#include <exception>
 #include <vector>
 
 #include "rt_device.hpp"
@@ -151,6 +153,27 @@ static int fail(rt_ctx* ctx, int code, const char* fmt, ...)
     return code;
 }
 
+// No C++ exception leaves the library (its callers bind a C ABI: ctypes, cgo, a C program): what a
+// std::vector or std::string throws inside an entry point becomes a status like any other failure.
+static int caught(rt_ctx* ctx, const char* where) noexcept
+{
+    int code = RT_ERR_INTERNAL;
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            code = RT_ERR_NOMEM;
+            return fail(ctx, code, "%s: out of host memory", where);
+        } catch (const std::exception& e) {
+            return fail(ctx, code, "%s: %s", where, e.what());
+        } catch (...) {
+            return fail(ctx, code, "%s: unknown failure", where);
+        }
+    } catch (...) { // not even the message could be stored
+        return code;
+    }
+}
+
 #define HIP_TRY(ctx, expr)                                                                                  \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
@@ -179,7 +202,7 @@ extern "C" {
 const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_lastError.c_str(); }
 
 int rt_ctx_create(int device_ordinal, rt_ctx** out)
-{
+try {
     if (!out)
         return fail(nullptr, RT_ERR_INVALID, "rt_ctx_create: out is NULL");
     *out = nullptr;
@@ -239,6 +262,8 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         ctx->workspaceCap = static_cast<size_t>(std::max(1.0, atof(s) * 1024.0)) << 20; // fractions allowed, at least 1 MiB
     *out = ctx;
     return RT_OK;
+} catch (...) {
+    return caught(nullptr, "rt_ctx_create");
 }
 
 void rt_ctx_destroy(rt_ctx* ctx)
@@ -580,7 +605,7 @@ struct HostBuilder {
 
 int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_node* nodes_out, rt_primitive* prims_out,
     uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves)
-{
+try {
     if ((n && !prims_in) || !nodes_out || (n && !prims_out) || !n_nodes || !n_levels || !n_leaves)
         return fail(nullptr, RT_ERR_INVALID, "rt_bvh_build: NULL argument");
     HostBuilder b;
@@ -629,6 +654,8 @@ int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_n
     *n_levels = numLevels;
     *n_leaves = numLeaves;
     return RT_OK;
+} catch (...) {
+    return caught(nullptr, "rt_bvh_build");
 }
 
 // ---------------------------------------------------------------------------
@@ -637,7 +664,7 @@ int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_n
 int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const rt_primitive* prims, uint32_t n_prims,
     const rt_material* mesh_materials, uint32_t n_meshes, const rt_image* images, uint32_t n_images,
     const int32_t env_faces[6], const rt_sphere* spheres, uint32_t n_spheres, uint64_t* generation)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_scene_upload: ctx is NULL");
     if (!nodes || n_nodes == 0)
@@ -899,10 +926,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
     if (generation)
         *generation = ctx->generation;
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_scene_upload");
 }
 
 int rt_lights_set(rt_ctx* ctx, const rt_light* lights, uint32_t n)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_lights_set: ctx is NULL");
     if (n && !lights)
@@ -924,10 +953,12 @@ int rt_lights_set(rt_ctx* ctx, const rt_light* lights, uint32_t n)
     ctx->scene.lights = ctx->dLights;
     ctx->scene.nLights = static_cast<int32_t>(n);
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_lights_set");
 }
 
 int rt_features_set(rt_ctx* ctx, const rt_features* f)
-{
+try {
     if (!ctx || !f)
         return fail(ctx, RT_ERR_INVALID, "rt_features_set: NULL argument");
     if (f->enableMotionBlur)
@@ -943,6 +974,8 @@ int rt_features_set(rt_ctx* ctx, const rt_features* f)
     ctx->features = *f;
     ctx->haveFeatures = true;
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_features_set");
 }
 
 } // extern "C"
@@ -1359,7 +1392,7 @@ size_t rt_shard_floats(int width, int height, int shard_index, int shard_count)
 }
 
 int rt_render(rt_ctx* ctx, const rt_camera* camera, int width, int height, float* out_rgb, rt_stats* stats)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_render: ctx is NULL");
     if (!out_rgb)
@@ -1387,11 +1420,13 @@ int rt_render(rt_ctx* ctx, const rt_camera* camera, int width, int height, float
     if (stats)
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_render");
 }
 
 int rt_render_device(rt_ctx* ctx, const rt_camera* camera, int width, int height, int shard_index, int shard_count,
     void* d_out, size_t d_out_floats, void* stream, int collect_stats, rt_stats* stats)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_render_device: ctx is NULL");
     const auto t0 = std::chrono::steady_clock::now();
@@ -1409,10 +1444,12 @@ int rt_render_device(rt_ctx* ctx, const rt_camera* camera, int width, int height
             stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_render_device");
 }
 
 int rt_postprocess_device(rt_ctx* ctx, void* d_frame, int width, int height, void* stream)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_postprocess_device: ctx is NULL");
     if (!ctx->haveFeatures)
@@ -1421,10 +1458,12 @@ int rt_postprocess_device(rt_ctx* ctx, void* d_frame, int width, int height, voi
         return fail(ctx, RT_ERR_INVALID, "rt_postprocess_device: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return bloomDevice(ctx, static_cast<float*>(d_frame), width, height, static_cast<hipStream_t>(stream));
+} catch (...) {
+    return caught(ctx, "rt_postprocess_device");
 }
 
 int rt_pack_bmp_device(rt_ctx* ctx, const void* d_frame, int width, int height, void* d_bgra, void* stream)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_pack_bmp_device: ctx is NULL");
     if (!d_frame || !d_bgra || width <= 0 || height <= 0)
@@ -1432,10 +1471,12 @@ int rt_pack_bmp_device(rt_ctx* ctx, const void* d_frame, int width, int height, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launchPackBmp(static_cast<hipStream_t>(stream), static_cast<const float*>(d_frame), static_cast<uint8_t*>(d_bgra), width, height));
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_pack_bmp_device");
 }
 
 int rt_write_bmp(rt_ctx* ctx, const float* rgb, int width, int height, const char* path)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_write_bmp: ctx is NULL");
     if (!rgb || !path || width <= 0 || height <= 0)
@@ -1469,6 +1510,8 @@ int rt_write_bmp(rt_ctx* ctx, const float* rgb, int width, int height, const cha
     if (wrote != file.size())
         return fail(ctx, RT_ERR_INVALID, "rt_write_bmp: short write to %s", path);
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_write_bmp");
 }
 
 size_t rt_bmp_header(int width, int height, uint8_t* out, size_t out_bytes)
@@ -1498,7 +1541,7 @@ size_t rt_bmp_header(int width, int height, uint8_t* out, size_t out_bytes)
 }
 
 int rt_sync(rt_ctx* ctx, void* stream, rt_stats* stats)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_sync: ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1508,10 +1551,12 @@ int rt_sync(rt_ctx* ctx, void* stream, rt_stats* stats)
         return readStats(ctx, stats, true);
     }
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_sync");
 }
 
 int rt_deinterleave(rt_ctx* ctx, const void* d_packed, int width, int height, int shard_count, void* d_frame, void* stream)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_deinterleave: ctx is NULL");
     if (!d_packed || !d_frame || width <= 0 || height <= 0 || shard_count <= 0)
@@ -1522,10 +1567,12 @@ int rt_deinterleave(rt_ctx* ctx, const void* d_packed, int width, int height, in
     HIP_TRY(ctx, launchDeinterleave(static_cast<hipStream_t>(stream), static_cast<const float*>(d_packed),
                       static_cast<float*>(d_frame), width, height, tilesX, tilesY, shard_count, stride));
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_deinterleave");
 }
 
 int rt_intersect_batch(rt_ctx* ctx, rt_ray* rays, uint32_t n, rt_hit* hits)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_intersect_batch: ctx is NULL");
     if (!ctx->haveScene)
@@ -1561,10 +1608,12 @@ int rt_intersect_batch(rt_ctx* ctx, rt_ray* rays, uint32_t n, rt_hit* hits)
     if (e != hipSuccess)
         return fail(ctx, RT_ERR_DEVICE, "rt_intersect_batch: %s", hipGetErrorString(e));
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_intersect_batch");
 }
 
 int rt_eval_batch(rt_ctx* ctx, int kind, const float* in, uint32_t n, float* out, const void* aux)
-{
+try {
     if (!ctx)
         return fail(nullptr, RT_ERR_INVALID, "rt_eval_batch: ctx is NULL");
     static const int inW[] = { 12, 12, 9, 3, 3, 2, 3, 2, 2, 20 };
@@ -1626,6 +1675,8 @@ int rt_eval_batch(rt_ctx* ctx, int kind, const float* in, uint32_t n, float* out
     if (e != hipSuccess)
         return fail(ctx, RT_ERR_DEVICE, "rt_eval_batch: %s", hipGetErrorString(e));
     return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_eval_batch");
 }
 
 } // extern "C"
