@@ -422,6 +422,36 @@ def test_device_unit_functions_match_reference_tests_and_oracle(ctx):
         assert np.array_equal(ctx.sampler_next(seed, 64), orc.sampler_next(seed, 64))
 
 
+def test_shading_models_bit_for_bit(ctx):
+    """computeShading (src/shading.cpp:30-213) on the device against the oracle, every model, random
+    unit vectors, colours and shininess values: the same bits, the specular powers included (they are
+    taken the way the host's C library takes them)."""
+    rng = np.random.default_rng(11)
+    n = 400
+
+    def unit(k):
+        v = rng.normal(size=(k, 3)).astype(np.float32)
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    ctx.upload_scene(common.scene("SingleTriangle"))
+    for shading, model in ((0, 0), (1, 0), (1, 1), (1, 2), (1, 3)):
+        f = common.features(enableShading=shading, shadingModel=model)
+        ctx.set_features(f)
+        rec = np.zeros((n, 20), dtype=np.float32)
+        rec[:, 0:3] = rng.uniform(0, 1, (n, 3))
+        rec[:, 3:6] = rng.uniform(0, 1, (n, 3))
+        rec[:, 6] = np.where(rng.uniform(size=n) < 0.5, np.floor(rng.uniform(1, 200, n)), rng.uniform(0.1, 500, n))
+        rec[:, 8:11], rec[:, 11:14], rec[:, 14:17] = unit(n), unit(n), unit(n)
+        rec[:, 17:20] = rng.uniform(0, 1, (n, 3))
+        got = ctx.eval(capi.EVAL_SHADING, rec)
+        want = np.zeros((n, 3), dtype=np.float32)
+        for i in range(n):
+            m = sio.make_material(kd=rec[i, 0:3], ks=rec[i, 3:6], shininess=rec[i, 6])
+            want[i] = orc.compute_shading(f, m, rec[i, 8:11], rec[i, 11:14], rec[i, 14:17], rec[i, 17:20])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (shading, model, np.abs(got - want).max())
+        assert want.any()
+
+
 def test_camera_rays_and_primary_hit_ids(ctx):
     """Primary-hit primitive index and t per pixel against the oracle: required
     agreement 99.9 % of pixels, observed here: all of them, t bit for bit."""
