@@ -422,6 +422,20 @@ def test_device_unit_functions_match_reference_tests_and_oracle(ctx):
         assert np.array_equal(ctx.sampler_next(seed, 64), orc.sampler_next(seed, 64))
 
 
+def test_sampler_stream_and_texcoord_interpolation_on_the_device(ctx):
+    """Sampler::next_1d (src/sampler.h:16-45) and interpolateTexCoord (src/interpolate.cpp:50-55) as the
+    kernels compute them, against the oracle: the same bits."""
+    ctx.upload_scene(common.scene("SingleTriangle"))
+    ctx.set_features(common.features())
+    for seed in (0, 123, 1080 * 17 + 5, 13 * 15 + 11, 2**32 - 1):
+        assert np.array_equal(ctx.sampler_next(seed, 700).view(np.uint32), orc.sampler_next(seed, 700).view(np.uint32))
+    rng = np.random.default_rng(3)
+    rec = rng.uniform(-1, 2, (300, 9)).astype(np.float32)
+    got = ctx.eval(capi.EVAL_INTERP_TEXCOORD, rec)
+    want = np.array([orc.interpolate_texcoord(r[0:2], r[2:4], r[4:6], r[6:9]) for r in rec], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_shading_models_bit_for_bit(ctx):
     """computeShading (src/shading.cpp:30-213) on the device against the oracle, every model, random
     unit vectors, colours and shininess values: the same bits, the specular powers included (they are
