@@ -87,6 +87,7 @@ struct rt_ctx {
     float* dBloom = nullptr; // thresholded copy of the frame for the bloom pass
     size_t bloomCap = 0;     // floats
     uint4* dPairs = nullptr;
+    bool strictIntersect = false; // rt_intersect_batch replays every ray in the reference's order of tests
     uint4* dRefNodes = nullptr; // the caller's nodes as they came (replay of the reference's order of tests)
     uint32_t numPairs = 0; // pair records in dPairs
     float4* dTris = nullptr;
@@ -254,6 +255,8 @@ try {
         ctx->shadowBlocksPerCU = atoi(s);
     if (const char* s = getenv("RT_AMD_PATH_BLOCKS_PER_CU"))
         ctx->pathBlocksPerCU = atoi(s);
+    if (const char* s = getenv("RT_AMD_STRICT_INTERSECT"))
+        ctx->strictIntersect = atoi(s) != 0;
     if (const char* s = getenv("RT_AMD_TREE"))
         ctx->treeMode = atoi(s);
     if (const char* s = getenv("RT_AMD_PER_PIXEL"))
@@ -915,6 +918,7 @@ try {
     s.nPrims = n_prims;
     s.tieByIndex = (ownTree && ctx->treeMode == 2) ? 1 : 0;
     s.refNodes = replayable ? ctx->dRefNodes : nullptr;
+    s.strictIntersect = ctx->strictIntersect ? 1 : 0;
     s.nMeshes = static_cast<int32_t>(n_meshes);
     s.nSpheres = static_cast<int32_t>(n_spheres);
     s.nTex = static_cast<int32_t>(n_images);

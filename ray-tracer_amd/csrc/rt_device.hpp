@@ -141,6 +141,11 @@ struct DevScene {
     // upper, data[2]); only read when a ray has to be replayed in the reference's order of tests
     // (Tracer::settleTie).  Null when the caller's tree is deeper than a lane's stack.
     const uint4* refNodes;
+    // rt_intersect_batch only: replay every ray that way (RT_AMD_STRICT_INTERSECT=1).  The reference's own box
+    // test is not conservative: a ray aimed exactly at a vertex or at the corner of a leaf's box can
+    // miss, by rounding, a box that holds its hit, and the reference then reports the next hit or none,
+    // where the traversal here (whose box tests never lose a hit) reports the nearer one.
+    int32_t strictIntersect;
 };
 
 struct DevCamera {

@@ -520,6 +520,8 @@ __global__ __launch_bounds__(kBlockThreads) void intersectKernel(const DevScene 
     tracer.run(L, (16 << 8) | (32 << 16)); // every ray to completion, default switch points
     if (i >= n)
         return;
+    if (sc.strictIntersect)
+        L.tie = true;
     tracer.settleTie(L);
     tracer.spheres(L);
     rt_hit h;

@@ -1,0 +1,68 @@
+"""Rays aimed at the places where rounding decides: exactly at vertices, at points on edges and at
+corners of leaf boxes of a scene, from random origins.  Device (rt_intersect_batch) against the
+oracle, which tests boxes the reference's non-conservative way: hit flag, t and primitive per ray.
+
+    python tools/fuzz_edges.py [scene] [rays-per-kind] [seeds]
+
+With RT_AMD_STRICT_INTERSECT=1 in the environment the device replays every ray in the reference's own
+order of tests and must agree on every ray.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import common  # noqa: E402
+import orc  # noqa: E402
+
+sio = importlib.import_module("ray-tracer_amd.scene_io")
+capi = importlib.import_module("ray-tracer_amd.capi")
+name = sys.argv[1] if len(sys.argv) > 1 else "Teapot"
+per = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+scn = common.scene(name)
+osc = orc.OracleScene(scn)
+ctx = capi.Context(0)
+ctx.upload_scene(scn)
+f = common.features()
+ctx.set_features(f)
+prims = osc.prims
+P = np.stack([prims["v0"]["position"], prims["v1"]["position"], prims["v2"]["position"]], axis=1).astype(np.float32)  # (n, 3, 3)
+nodes = osc.nodes
+leaf = (nodes["data"][:, 0] & 0x80000000) != 0
+corners_lo, corners_hi = nodes["lower"][leaf], nodes["upper"][leaf]
+total = bad = 0
+for seed in range(seeds):
+    rng = np.random.default_rng(seed)
+    targets = []
+    t = rng.integers(0, len(P), per)
+    targets.append(P[t, rng.integers(0, 3, per)])                                  # vertices
+    a = rng.uniform(0, 1, (per, 1)).astype(np.float32)
+    k = rng.integers(0, 3, per)
+    targets.append((P[t, k] * a + P[t, (k + 1) % 3] * (np.float32(1) - a)).astype(np.float32))  # points on edges
+    b = rng.integers(0, len(corners_lo), per)
+    pick = rng.integers(0, 2, (per, 3)).astype(bool)
+    targets.append(np.where(pick, corners_lo[b], corners_hi[b]).astype(np.float32))  # corners of leaf boxes
+    for kind, tg in zip(("vertices", "edge points", "box corners"), targets):
+        o = rng.uniform(-2, 2, tg.shape).astype(np.float32)
+        if kind == "vertices":  # some along an axis: zero direction components
+            ax = rng.integers(0, 3, len(o))
+            sel = rng.uniform(size=len(o)) < 0.2
+            o[sel] = tg[sel]
+            o[sel, ax[sel]] += np.float32(1.5)
+        d = tg - o
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        rays = np.zeros(len(o), dtype=sio.RAY)
+        rays["origin"], rays["direction"], rays["t"] = o, d, np.finfo(np.float32).max
+        r_o, h_o, _ = osc.intersect(f, rays)
+        r_g, h_g = ctx.intersect(rays)
+        diff = (h_o["hit"] != h_g["hit"]) | (r_o["t"].view(np.uint32) != r_g["t"].view(np.uint32)) | (h_o["primitive"] != h_g["primitive"])
+        total += len(rays)
+        bad += int(diff.sum())
+        print(f"seed {seed}, {kind}: {len(rays)} rays, {int(h_o['hit'].sum())} hits, {int(diff.sum())} differ", flush=True)
+        for i in np.nonzero(diff)[0][:3]:
+            print("   o", o[i], "d", d[i], "| oracle", h_o["hit"][i], h_o["primitive"][i], r_o["t"][i], "| device", h_g["hit"][i], h_g["primitive"][i], r_g["t"][i])
+print(f"{name}: {total} rays, {bad} differ")
