@@ -9,11 +9,20 @@ samples, reflections with a depth cap of 4, default camera.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by torch.distributed.run, one rank per GPU: every rank
-renders its interleaved 8x8 tiles of the frame (scene and BVH replicated, no
-data-path collective), the only collective is the RCCL gather of the packed
-tile buffers to rank 0, which scatters them into Screen order.  The frame is
-the same whatever N is, so scaling is "strong".
+N > 1 runs one rank per GPU under torch.distributed.run.  Started by such a
+launcher (RANK / WORLD_SIZE in the environment) the process is one rank of the
+job; started plainly as `python bench.py --gpus N`, it starts the launcher
+itself as a child process -- before this process has made any GPU call -- and
+passes on rank 0's JSON line and the exit status.  Every rank renders its
+interleaved 8x8 tiles of the frame (scene and BVH replicated, no data-path
+collective), the only collective is the RCCL gather of the packed tile buffers
+to rank 0, which scatters them into Screen order.  The frame is the same
+whatever N is, so scaling is "strong".
+
+`--launch-check` runs the N > 1 control flow without a GPU: the ranks
+rendezvous over gloo, "render" their tiles of a synthetic frame on the CPU,
+gather, de-interleave, reduce the timings like the real run, and rank 0 prints
+one JSON line with the ranks the collective library saw.
 
 Frames in flight: consecutive steps go round-robin to `--in-flight` (default 3, 4 when N > 1) contexts, each
 with its own stream, workspace and output buffers, the way a double- or triple-buffered
@@ -46,8 +55,12 @@ sys.path.insert(0, ROOT)
 # GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams on one queue run one after the
 # other (measured at N = 1: a fourth frame in flight on four queues costs 12 %, on eight it does not).
 # Has to be set before the HIP runtime starts; RT_BENCH_HW_QUEUES overrides the 8.
+def _hw_queues_for_many_ranks(env):
+    env["GPU_MAX_HW_QUEUES"] = env.get("RT_BENCH_HW_QUEUES", "8")
+
+
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "8")
+    _hw_queues_for_many_ranks(os.environ)
 
 sio = importlib.import_module("ray-tracer_amd.scene_io")
 capi = importlib.import_module("ray-tracer_amd.capi")
@@ -98,27 +111,28 @@ def build_workload(name: str):
 
 
 def cpu_baseline(scene, features, width, height, scale: int, distance: float = 3.0):
-    """The CPU oracle (a port of renderImage, OpenMP over rows like
-    src/render.cpp:27-29) on the same workload at 1/scale of the resolution."""
+    """The CPU oracle (a port of renderImage, OpenMP over rows like src/render.cpp:27-29) on the
+    same workload: at the workload's own size one frame (about ten seconds of all host cores for
+    the headline frame), at 1/scale of the resolution the median of three."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     osc = orc.OracleScene(scene)
     w, h = width // scale, height // scale
     cam = sio.default_camera(w, h, distance=distance)
     times = []
-    for _ in range(3):
+    for _ in range(1 if scale == 1 else 3):
         t0 = time.perf_counter()
         _, st = osc.render(features, cam, w, h, policy=0, threads=0)
         times.append(time.perf_counter() - t0)
-    dt = sorted(times)[1]
+    dt = sorted(times)[len(times) // 2]
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
     cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    size = f"the whole workload ({w}x{h}), one frame" if scale == 1 else f"same scene/features at {w}x{h} (1/{scale * scale} of the pixels), median of 3 frames"
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"same scene/features at {w}x{h} (1/{scale * scale} of the pixels), median of 3 frames, {dt:.1f} s each, "
-                      f"{st['rays']} rays"}
+            "sample": f"{size}, {dt:.1f} s, {st['rays']} rays", "rays": int(st["rays"])}
 
 
 def measured_traffic(workload, kernel, world, width, height, distance=3.0):
@@ -139,6 +153,74 @@ def measured_traffic(workload, kernel, world, width, height, distance=3.0):
     return k["fetch_bytes"] + k["write_bytes"], doc["source"] + "; " + doc["summary"]
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: start torch.distributed.run with N ranks
+    of this same command as a child process and hand back its exit status.  Runs before this
+    process has imported torch.cuda or made any HIP call; the ranks are fresh processes (a
+    process that has touched the GPU must not be replaced by another program)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    _hw_queues_for_many_ranks(env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC handles on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def reduce_over_ranks(dt: float, rays: float, world: int, dist, device):
+    """(max over ranks of the timed region, sum over ranks of the rays of one frame)."""
+    import torch
+    t_all = torch.tensor([dt, rays], dtype=torch.float64, device=device)
+    if world == 1:
+        return dt, rays
+    tmax, tsum = t_all.clone(), t_all.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    return float(tmax[0]), float(tsum[1])
+
+
+def launch_check(args, rank: int, world: int):
+    """The control flow of an N-rank run with the GPU taken out: rendezvous (gloo), every rank
+    fills its own tiles of a synthetic frame, the one gather, rank 0's de-interleave, the
+    reduction of the timings.  Rank 0 prints what the collective library saw."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h = 100, 52  # partial tiles on both edges
+    ys, xs = np.mgrid[0:h, 0:w]
+    frame = np.stack([xs, ys, xs * 1000 + ys], axis=-1).astype(np.float32)
+    stride = sharding.shard_floats(w, h, 0, world) if world > 1 else w * h * 3
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        if world > 1:
+            packed = torch.from_numpy(sharding.pack_shard(frame, rank, world))
+            gathered = torch.empty((world, stride), dtype=torch.float32) if rank == 0 else None
+            sharding.gather_packed(packed, rank, world, dist, gathered)
+            whole = sharding.deinterleave(gathered.numpy(), w, h, world) if rank == 0 else None
+        else:
+            whole = frame
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    mine = float(sharding.shard_tiles(w, h, rank, world))
+    dt_max, units = reduce_over_ranks(dt, mine, world, dist, torch.device("cpu"))
+    seen = dist.get_world_size() if world > 1 else 1
+    if rank == 0:
+        ok = bool(np.array_equal(whole, frame)) and int(units) == ((w + 7) // 8) * ((h + 7) // 8)
+        print(json.dumps({"launch_check": ok, "n_gpus": args.gpus, "world_size": seen, "tiles": int(units),
+                          "max_rank_seconds": round(dt_max, 4)}), flush=True)
+        if not ok:
+            raise SystemExit("launch check: the gathered frame differs from the synthetic one")
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,20 +230,34 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-scale", type=int, default=2)
+    ap.add_argument("--cpu-scale", type=int, default=0,
+                    help="CPU baseline at 1/scale of the resolution; 0 = the workload's own size when that is at most 120 M rays "
+                         "(the headline frame: 69 M), else the smallest power of two that gets it there")
     ap.add_argument("--camera-distance", type=float, default=3.0,
                     help="the reference's default camera is at 3.0 (src/config.h:18-23); 1.6 fills the frame with the model")
     ap.add_argument("--in-flight", type=int, default=0, help="frames in flight (contexts/streams used round-robin)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="run the N-rank control flow (launcher, rendezvous, gather, reductions) on the CPU over gloo and leave")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))  # this process never touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): use --nproc-per-node {args.gpus}")
+    if args.launch_check:
+        return launch_check(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+
+    if torch.cuda.device_count() < world:  # (counting devices does not start the GPU runtime)
+        raise SystemExit(f"--gpus {world} but this node shows {torch.cuda.device_count()} GPU(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rendering path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -243,16 +339,8 @@ def main():
     # launches of every kernel per frame
     per_frame = max(1, st["batches"] // nl)
 
-    rays_local = float(st["rays"])
-    t_all = torch.tensor([dt, rays_local], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = t_all.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t_all.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, rays_total = float(tmax[0]), float(tsum[1])
-    else:
-        dt_max, rays_total = dt, rays_local
+    dt_max, rays_total = reduce_over_ranks(dt, float(st["rays"]), world, dist, dev)
+    ranks_seen = dist.get_world_size() if world > 1 else 1  # what the collective library itself counts
 
     # one frame on its own (outside the timed region): the kernels' durations when they do not share
     # the compute units with a neighbouring frame's kernels
@@ -286,7 +374,7 @@ def main():
         out = {
             "metric": "Mrays/s (whole node) on dragon.obj 1080p 16spp; ms/frame" if args.workload == "dragon"
                       else f"Mrays/s ({args.workload})",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "world_size": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -313,7 +401,15 @@ def main():
                                              "shadowTraceKernel": round(shadow_ms, 4)}},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(scene, features, width, height, args.cpu_scale, args.camera_distance)
+            scale = args.cpu_scale
+            if scale <= 0:
+                scale = 1
+                while rays_total / (scale * scale) > 1.2e8:
+                    scale *= 2
+            cb = cpu_baseline(scene, features, width, height, scale, args.camera_distance)
+            if scale == 1:  # same frame on both sides: the two ray counts have to be the same number
+                cb["rays_equal_device"] = cb["rays"] == int(rays_total)
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

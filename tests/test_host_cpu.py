@@ -187,3 +187,26 @@ def test_world_size_2_tile_gather_over_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GLOO_OK" in out.stdout
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_bench_starts_its_own_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: the parent starts torch.distributed.run
+    as a child before touching the GPU, the ranks rendezvous (gloo here), gather their tiles, reduce
+    their timings and rank 0 prints one JSON line naming the ranks the collective library saw."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", str(n), "--launch-check", "--steps", "2"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    assert lines[0]["launch_check"] is True and lines[0]["world_size"] == n and lines[0]["n_gpus"] == n
+    assert lines[0]["tiles"] == 13 * 7
+
+
+def test_bench_refuses_a_launcher_of_another_size():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "4" in out.stderr
