@@ -232,6 +232,23 @@ int rt_render_device(rt_ctx* ctx, const rt_camera* camera, int width, int height
                      int collect_stats, rt_stats* stats);
 size_t rt_shard_floats(int width, int height, int shard_index, int shard_count);
 
+/* rt_render_device for callers that cannot allocate device memory while they run: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
+ * reference.  Same frame, same arguments, same bits as rt_render_device, but the call allocates
+ * nothing (no hipMalloc, no event, no stream): counters, ray queues, the pools of hits and light
+ * samples and the bloom copy are carved from a static array in device memory,
+ * RT_NOALLOC_SCRATCH_BYTES per GPU, which every GPU the library has a context on holds until the
+ * process ends.  A frame whose working set exceeds it is rendered in more pixel batches (slower, the
+ * same result); refused with RT_ERR_UNSUPPORTED are a frame of which one 8x8 tile alone needs more
+ * than the scratch (hundreds of camera rays per pixel times many light samples at a deep ray depth)
+ * and, with bloom on and shard_count == 1, a frame whose copy (width * height * 12 bytes) does not
+ * fit.  No timing is taken (events are allocations); rt_sync still returns the ray count.  The
+ * scratch is one per GPU, not per context: calls that overlap on one GPU (two streams, two contexts)
+ * race, and so do a call here and the stats read of an earlier one. */
+#define RT_NOALLOC_SCRATCH_BYTES ((size_t)128 << 20)
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_camera* camera, int width, int height, int shard_index,
+                             int shard_count, void* d_out, size_t d_out_floats, void* stream);
+
 /* Scatter shard_count packed tile buffers (as laid end to end by a gather,
  * each rt_shard_floats(.., 0, shard_count) floats apart) into a frame in
  * Screen order.  Device pointers; enqueued on `stream`. */

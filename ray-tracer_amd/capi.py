@@ -18,6 +18,7 @@ EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_bvh_build", "rt_scene_upload", "rt_lights_set",
     "rt_features_set", "rt_render", "rt_render_device", "rt_shard_floats", "rt_deinterleave", "rt_sync",
     "rt_intersect_batch", "rt_eval_batch", "rt_postprocess_device", "rt_pack_bmp_device", "rt_bmp_header", "rt_write_bmp",
+    "rt_render_device_noalloc",
 ]
 
 (EVAL_BARYCENTRIC, EVAL_INTERP_NORMAL, EVAL_INTERP_TEXCOORD, EVAL_TEX_NEAREST, EVAL_TEX_BILINEAR,
@@ -177,6 +178,12 @@ class Context:
                                            C.c_void_p(d_out_ptr), C.c_size_t(d_out_floats), C.c_void_p(stream),
                                            int(bool(collect_stats)), C.byref(st)))
         return st.as_dict() if collect_stats else None
+
+    def render_device_noalloc(self, camera, width, height, d_out_ptr: int, d_out_floats: int, shard=0, n_shard=1, stream: int = 0):
+        """rt_render_device without any allocation: working buffers come from the library's static scratch."""
+        cam = np.ascontiguousarray(camera, dtype=sio.CAMERA)
+        self._check(lib().rt_render_device_noalloc(self.handle, _p(cam), int(width), int(height), int(shard), int(n_shard),
+                                                   C.c_void_p(d_out_ptr), C.c_size_t(d_out_floats), C.c_void_p(stream)))
 
     def deinterleave(self, d_packed_ptr: int, width, height, n_shard, d_frame_ptr: int, stream: int = 0):
         self._check(lib().rt_deinterleave(self.handle, C.c_void_p(d_packed_ptr), int(width), int(height), int(n_shard),

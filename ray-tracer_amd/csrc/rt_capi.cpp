@@ -16,6 +16,7 @@
 #include <limits>
 #include <string>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <exception>
 #include <vector>
@@ -40,6 +41,34 @@ hipError_t launchEval(hipStream_t stream, const DevScene& sc, const DevCamera& c
 using namespace rt;
 
 static thread_local std::string g_lastError;
+
+// Scratch of the entry point that allocates nothing (rt_render_device_noalloc): counters, queues,
+// the hit and light-sample pools of one pixel batch and the bloom copy live here instead of in
+// buffers from hipMalloc.  Every GPU the library runs on holds its own copy of the array, at its
+// own address, until the process ends; host code never uses the array's name as an address but the
+// per-device pointer hipGetSymbolAddress returned when the first context on that device was made.
+constexpr size_t kScratchBytes = RT_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+static void* g_scratchPtr[kMaxDevices] = {};
+static std::mutex g_scratchMutex;
+
+// The device address of `scratch` on `device`, which must be the current device.
+static hipError_t scratchOnDevice(int device, void** out)
+{
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (device < 0 || device >= kMaxDevices)
+        return hipErrorInvalidDevice;
+    if (!g_scratchPtr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess)
+            return e;
+        g_scratchPtr[device] = p;
+    }
+    *out = g_scratchPtr[device];
+    return hipSuccess;
+}
 
 struct TreeLeaf {
     float lo[3], hi[3], c[3];
@@ -139,6 +168,18 @@ struct rt_ctx {
     // wavefront workspace (grow-only)
     void* wsPtr[10] = {};
     size_t wsBytes[10] = {};
+    // this device's copy of the static scratch array (rt_render_device_noalloc); null on a device
+    // ordinal beyond the table
+    void* scratchPtr = nullptr;
+    DevCounters* lastCounters = nullptr; // where the last render's counters live (dCounters or the scratch)
+    // resident blocks per compute unit of the kernels the current scene and features select, asked
+    // of the runtime when either changes so that a render call has nothing left to ask
+    struct Occupancy {
+        bool valid = false;
+        size_t lds = 0;
+        int transp = -1, variant = -1;
+        int path = 0, shadow = 0, render = 0;
+    } occ;
 };
 
 static int fail(rt_ctx* ctx, int code, const char* fmt, ...)
@@ -182,6 +223,8 @@ static int caught(rt_ctx* ctx, const char* where) noexcept
             return fail(ctx, RT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+static int warmOccupancy(rt_ctx* ctx);
+
 template <typename T>
 static hipError_t uploadVec(T** dptr, const std::vector<T>& v)
 {
@@ -220,6 +263,15 @@ try {
     if (hipMalloc(reinterpret_cast<void**>(&ctx->dCounters), sizeof(DevCounters)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, RT_ERR_DEVICE, "rt_ctx_create: device allocation failed");
+    }
+    ctx->lastCounters = ctx->dCounters;
+    if (device_ordinal < kMaxDevices) { // this device's address of the static scratch array, once per device
+        const hipError_t e = scratchOnDevice(device_ordinal, &ctx->scratchPtr);
+        if (e != hipSuccess) {
+            (void)hipFree(ctx->dCounters);
+            delete ctx;
+            return fail(nullptr, RT_ERR_DEVICE, "rt_ctx_create: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e));
+        }
     }
     if (const char* s = getenv("RT_AMD_MIN_ACTIVE"))
         ctx->minActive = ctx->minActiveShadow = atoi(s);
@@ -929,7 +981,7 @@ try {
     ctx->generation++;
     if (generation)
         *generation = ctx->generation;
-    return RT_OK;
+    return warmOccupancy(ctx);
 } catch (...) {
     return caught(ctx, "rt_scene_upload");
 }
@@ -977,7 +1029,7 @@ try {
         return fail(ctx, RT_ERR_INVALID, "rt_features_set: maxRayDepth %d not in [0, %d]", f->maxRayDepth, kMaxDepth);
     ctx->features = *f;
     ctx->haveFeatures = true;
-    return RT_OK;
+    return warmOccupancy(ctx);
 } catch (...) {
     return caught(ctx, "rt_features_set");
 }
@@ -1057,13 +1109,77 @@ static size_t shardTiles(int width, int height, int shard, int nShard)
     return (tiles > static_cast<size_t>(shard)) ? (tiles - shard + nShard - 1) / nShard : 0;
 }
 
+// A fixed piece of device memory a render call carves its working buffers from instead of
+// allocating them (rt_render_device_noalloc: this device's copy of the static scratch array).
+struct Arena {
+    char* base;
+    size_t bytes, used;
+    void* take(size_t n)
+    {
+        const size_t at = (used + 255) & ~size_t(255);
+        if (at + n > bytes)
+            return nullptr;
+        used = at + n;
+        return base + at;
+    }
+};
+
+static size_t traversalLds(const rt_ctx* ctx)
+{
+    // A ray's stack holds the bottom marker and at most one waiting sibling per inner node on its path:
+    // a tree whose longest root-to-leaf path has L nodes needs L entries.
+    return static_cast<size_t>(std::max<uint32_t>(ctx->numLevels, 2)) * kBlockThreads * 4;
+}
+
+static int perPixelVariant(const rt_features& F, bool collect)
+{
+    int variant = 0;
+    if (F.enableTransparency)
+        variant |= 1;
+    if (F.enableGlossyReflection && F.enableReflections)
+        variant |= 2;
+    if (F.enableDepthOfField)
+        variant |= 4;
+    if (collect)
+        variant |= 8;
+    return variant;
+}
+
+// Resident blocks per compute unit of the traversing kernels under the current scene and features
+// (non-counting variants), asked of the runtime once per change of either: rt_scene_upload and
+// rt_features_set call this, so a render call finds the answer ready.
+static int warmOccupancy(rt_ctx* ctx)
+{
+    ctx->occ.valid = false;
+    if (!ctx->haveScene || !ctx->haveFeatures)
+        return RT_OK;
+    const rt_features& F = ctx->features;
+    rt_ctx::Occupancy o;
+    o.lds = traversalLds(ctx);
+    o.transp = F.enableTransparency != 0;
+    o.variant = perPixelVariant(F, false);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, wavefrontOccupancy(false, o.transp != 0, kBlockThreads, o.lds, &o.path, &o.shadow));
+    HIP_TRY(ctx, renderOccupancy(o.variant, kBlockThreads, o.lds, &o.render));
+    o.valid = true;
+    ctx->occ = o;
+    return RT_OK;
+}
+
 // postprocessImageWithBloom (src/extra.cpp:276-316) on a whole frame in Screen order, in place.
-static int bloomDevice(rt_ctx* ctx, float* dFrame, int width, int height, hipStream_t stream)
+// `copy`: room for the thresholded copy of the frame, or null to use the context's own buffer.
+static int bloomDevice(rt_ctx* ctx, float* dFrame, int width, int height, hipStream_t stream, float* copy = nullptr)
 {
     const rt_features& F = ctx->features;
     if (!F.enableBloomEffect)
         return RT_OK;
     const size_t floats = static_cast<size_t>(width) * height * 3;
+    if (copy) {
+        BloomWeights w;
+        bloomWeights(static_cast<int>(F.bloomFilterSize), w);
+        HIP_TRY(ctx, launchBloom(stream, dFrame, copy, width, height, static_cast<int>(F.bloomFilterSize), F.bloomThreshold, w));
+        return RT_OK;
+    }
     if (floats > ctx->bloomCap) {
         HIP_TRY(ctx, hipStreamSynchronize(stream));
         if (ctx->dBloom)
@@ -1085,8 +1201,11 @@ static int traceKnobs(int minActive, int a, int b)
     return c(minActive) | (c(a) << 8) | (c(b) << 16);
 }
 
+// `arena`: null = working buffers are the context's own (allocated and grown as needed); else they
+// are carved from it and the call allocates nothing, times nothing (events are allocations too) and
+// splits the frame into as many pixel batches as the arena's size asks for.
 static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int height, int shard, int nShard, float* dOut,
-    size_t dOutFloats, hipStream_t stream, bool collect, bool timeIt)
+    size_t dOutFloats, hipStream_t stream, bool collect, bool timeIt, Arena* arena = nullptr)
 {
     if (!ctx->haveScene)
         return fail(ctx, RT_ERR_STATE, "render: no scene uploaded (rt_scene_upload)");
@@ -1112,12 +1231,23 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
 
     const int blockThreads = kBlockThreads;
     const int maxPerCU = 32 / kBlockWaves; // a compute unit holds 32 wavefronts
-    // A ray's stack holds the bottom marker and at most one waiting sibling per inner node on its path:
-    // a tree whose longest root-to-leaf path has L nodes needs L entries.
-    const uint32_t stackEntries = std::max<uint32_t>(ctx->numLevels, 2);
-    const size_t lds = static_cast<size_t>(stackEntries) * blockThreads * 4;
+    const size_t lds = traversalLds(ctx);
+    const rt_features& F = ctx->features;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, collect ? sizeof(DevCounters) : offsetof(DevCounters, waveLog), stream));
+    DevCounters* dCounters = ctx->dCounters;
+    float* bloomCopy = nullptr;
+    if (arena) {
+        dCounters = static_cast<DevCounters*>(arena->take(sizeof(DevCounters)));
+        if (F.enableBloomEffect && nShard == 1) {
+            bloomCopy = static_cast<float*>(arena->take(static_cast<size_t>(width) * height * 12));
+            if (!bloomCopy)
+                return fail(ctx, RT_ERR_UNSUPPORTED, "render: the bloom copy of a %dx%d frame does not fit the %zu-byte scratch", width, height, arena->bytes);
+        }
+        if (!dCounters)
+            return fail(ctx, RT_ERR_INTERNAL, "render: scratch smaller than the counters");
+    }
+    ctx->lastCounters = dCounters;
+    HIP_TRY(ctx, hipMemsetAsync(dCounters, 0, collect ? sizeof(DevCounters) : offsetof(DevCounters, waveLog), stream));
     if (timeIt) {
         if (ctx->evUsed + 2 > ctx->evPool.size()) {
             if (ctx->evPool.size() >= 2 * 4096) { // unread launches pile up: fold them by waiting once
@@ -1134,27 +1264,27 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed], stream));
     }
 
-    const rt_features& F = ctx->features;
+    // the kernels' resident blocks per compute unit: as found when the scene / features were set, unless
+    // this is a counting launch (other variants) or something changed behind that
+    const bool occReady = !collect && ctx->occ.valid && ctx->occ.lds == lds && ctx->occ.transp == (F.enableTransparency != 0)
+        && ctx->occ.variant == perPixelVariant(F, false);
+    if (arena && !occReady)
+        return fail(ctx, RT_ERR_STATE, "render: launch geometry not prepared (rt_scene_upload and rt_features_set do that)");
     const bool perPixel = ctx->forcePerPixel || (F.enableGlossyReflection && F.enableReflections);
     if (perPixel) {
-        int variant = 0;
-        if (F.enableTransparency)
-            variant |= 1;
-        if (F.enableGlossyReflection && F.enableReflections)
-            variant |= 2;
-        if (F.enableDepthOfField)
-            variant |= 4;
-        if (collect)
-            variant |= 8;
+        const int variant = perPixelVariant(F, collect);
         int perCU = ctx->blocksPerCU;
         if (perCU <= 0) {
-            HIP_TRY(ctx, renderOccupancy(variant, blockThreads, lds, &perCU));
+            if (occReady)
+                perCU = ctx->occ.render;
+            else
+                HIP_TRY(ctx, renderOccupancy(variant, blockThreads, lds, &perCU));
             perCU = std::max(1, std::min(perCU, maxPerCU));
         }
         const uint32_t wavesNeeded = fr.nWork / 64;
         int blocks = std::min<int64_t>(static_cast<int64_t>(ctx->numCU) * perCU, (wavesNeeded + kBlockWaves - 1) / kBlockWaves);
         blocks = std::max(blocks, 1);
-        HIP_TRY(ctx, launchRender(variant, blocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, ctx->dCounters, dOut,
+        HIP_TRY(ctx, launchRender(variant, blocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, dCounters, dOut,
                           traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB), ctx->logicRounds));
     } else {
         // ---- wavefront path: work items are camera rays and light samples
@@ -1182,9 +1312,12 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         if (wp.R == 0 || wp.R > 65535u)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
         const bool dof = F.enableDepthOfField != 0;
-        int pathPerCU = 0, shadowPerCU = 0;
+        int pathPerCU = 0, shadowPerCU = 0, pathBlocksFixed = 0;
         const bool transp = F.enableTransparency != 0;
-        HIP_TRY(ctx, wavefrontOccupancy(collect, transp, blockThreads, lds, &pathPerCU, &shadowPerCU));
+        if (occReady)
+            pathPerCU = ctx->occ.path, shadowPerCU = ctx->occ.shadow;
+        else
+            HIP_TRY(ctx, wavefrontOccupancy(collect, transp, blockThreads, lds, &pathPerCU, &shadowPerCU));
         if (pathPerCU < 1 || shadowPerCU < 1)
             return fail(ctx, RT_ERR_DEVICE, "render: the traversing kernels do not fit a compute unit (%zu B of LDS)", lds);
         pathPerCU = std::min(pathPerCU, maxPerCU), shadowPerCU = std::min(shadowPerCU, maxPerCU);
@@ -1210,8 +1343,28 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             pathPerCU = std::min(ctx->forcePathPerCU, maxPerCU);
         if (ctx->forceShadowPerCU > 0)
             shadowPerCU = std::min(ctx->forceShadowPerCU, maxPerCU);
+        // per light sample: its contribution (12 B) and its ray, 32 B; with transparency the ray record also
+        // carries the light's colour (48 B) and a visibility byte goes with it
+        const uint64_t perItem = transp ? (12ull + 48 + 1) : (12ull + 32);
+        const uint64_t perNodeBytes = 64 + sizeof(NodeB) + perItem * std::max(1u, slots);
+        // node slots a wavefront of the path kernel reserves at a time; from a fixed arena the smallest
+        // the kernel knows, and only as many path blocks as keep the unused ends of those blocks within
+        // an eighth of the arena
+        wp.nodeBlockMax = arena ? 64u : kNodeBlock;
+        size_t workspaceCap = ctx->workspaceCap;
+        if (arena) {
+            workspaceCap = arena->bytes - arena->used;
+            const uint64_t perBlock = static_cast<uint64_t>(blockThreads / 64) * wp.nodeBlockMax * perNodeBytes;
+            const uint64_t blocksFit = std::max<uint64_t>(1, (workspaceCap / 8) / std::max<uint64_t>(1, perBlock));
+            if (static_cast<uint64_t>(ctx->numCU) * pathPerCU > blocksFit) {
+                pathPerCU = static_cast<int>(blocksFit / ctx->numCU); // 0: fewer blocks than compute units
+                if (pathPerCU == 0)
+                    pathBlocksFixed = static_cast<int>(blocksFit);
+            }
+        }
+        const int pathBlocksAll = pathBlocksFixed ? pathBlocksFixed : ctx->numCU * pathPerCU;
         // every wavefront of the path kernel may leave part of its last block of node slots unused
-        const uint64_t nodeSlack = static_cast<uint64_t>(ctx->numCU) * pathPerCU * (blockThreads / 64) * kNodeBlock;
+        const uint64_t nodeSlack = static_cast<uint64_t>(pathBlocksAll) * (blockThreads / 64) * wp.nodeBlockMax;
         // Hits one camera ray can make.  A hit below the depth cap has a mirror child if its material
         // has a ks, and with transparency a pass-through child if the material is not opaque
         // (src/recursive.cpp:43-63): a chain of maxRayDepth + 1 hits, unless some material asks for both.
@@ -1222,12 +1375,12 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         else if (mirrors || passes)
             nodesPerPath = static_cast<uint64_t>(F.maxRayDepth) + 1;
         const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * nodesPerPath;
-        // per light sample: its contribution (12 B) and its ray, 32 B; with transparency the ray record also
-        // carries the light's colour (48 B) and a visibility byte goes with it
-        const uint64_t perItem = transp ? (12ull + 48 + 1) : (12ull + 32);
         const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + 32 + (F.enableEnvironmentMap ? 12 : 0))
-            + nodesPerPixel * (64 + sizeof(NodeB) + perItem * std::max(1u, slots));
-        uint64_t batchSlots = ctx->workspaceCap / std::max<uint64_t>(1, bytesPerPixel);
+            + nodesPerPixel * perNodeBytes;
+        // (the context's own buffers are virtual memory that is only touched where hits exist; an arena
+        // is real: the unused ends of the node blocks and the buffers' alignment come out of it first)
+        const uint64_t fixedBytes = arena ? nodeSlack * perNodeBytes + 16 * 256 : 0;
+        uint64_t batchSlots = (workspaceCap > fixedBytes ? workspaceCap - fixedBytes : 0) / std::max<uint64_t>(1, bytesPerPixel);
         batchSlots = std::min<uint64_t>(batchSlots, 0x7fffffffull / wp.R);                                       // path index in 31 bits
         // item index (node * slots + slot) in 32 bits, with room for the queue head to run past the end
         // by one batch per wavefront
@@ -1237,41 +1390,53 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         batchSlots = std::min<uint64_t>(batchSlots, (nodeCap - nodeSlack) / nodesPerPixel);
         batchSlots = std::min<uint64_t>(batchSlots, fr.nWork) & ~63ull;
         if (batchSlots == 0)
-            return fail(ctx, RT_ERR_UNSUPPORTED, "render: one tile of this frame needs more than the %zu-byte workspace", ctx->workspaceCap);
+            return fail(ctx, RT_ERR_UNSUPPORTED, "render: one 8x8 tile of this frame needs %llu bytes of working memory, more than the %zu-byte %s",
+                static_cast<unsigned long long>(64 * bytesPerPixel + fixedBytes), workspaceCap, arena ? "scratch left" : "workspace");
         const uint64_t paths = batchSlots * wp.R, maxNodes = batchSlots * nodesPerPixel + nodeSlack;
         const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, slots);
         const size_t want[10] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
             F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
             static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * (transp ? 48 : 32), transp ? items : 16, static_cast<size_t>(paths) * 32 };
-        for (int i = 0; i < 10; i++) {
-            if (ctx->wsBytes[i] < want[i]) {
-                HIP_TRY(ctx, hipStreamSynchronize(stream));
-                if (ctx->wsPtr[i])
-                    (void)hipFree(ctx->wsPtr[i]);
-                ctx->wsPtr[i] = nullptr;
-                ctx->wsBytes[i] = 0;
-                HIP_TRY(ctx, hipMalloc(&ctx->wsPtr[i], want[i]));
-                ctx->wsBytes[i] = want[i];
+        void* ws[10];
+        if (arena) {
+            for (int i = 0; i < 10; i++) {
+                ws[i] = arena->take(want[i]);
+                if (!ws[i])
+                    return fail(ctx, RT_ERR_INTERNAL, "render: working buffers exceed the scratch (%zu of %zu bytes used, %zu more asked)",
+                        arena->used, arena->bytes, want[i]);
+            }
+        } else {
+            for (int i = 0; i < 10; i++) {
+                if (ctx->wsBytes[i] < want[i]) {
+                    HIP_TRY(ctx, hipStreamSynchronize(stream));
+                    if (ctx->wsPtr[i])
+                        (void)hipFree(ctx->wsPtr[i]);
+                    ctx->wsPtr[i] = nullptr;
+                    ctx->wsBytes[i] = 0;
+                    HIP_TRY(ctx, hipMalloc(&ctx->wsPtr[i], want[i]));
+                    ctx->wsBytes[i] = want[i];
+                }
+                ws[i] = ctx->wsPtr[i];
             }
         }
         WfBuffers wb {};
-        wb.pathHead = static_cast<int32_t*>(ctx->wsPtr[0]);
-        wb.pathCount = static_cast<uint8_t*>(ctx->wsPtr[1]);
-        wb.pathBase = static_cast<uint32_t*>(ctx->wsPtr[2]);
-        wb.pathEnv = static_cast<float*>(ctx->wsPtr[3]);
-        wb.nodeA = static_cast<float4*>(ctx->wsPtr[4]);
-        wb.nodeB = static_cast<NodeB*>(ctx->wsPtr[5]);
-        wb.contrib = static_cast<float*>(ctx->wsPtr[6]);
-        wb.srays = static_cast<float4*>(ctx->wsPtr[7]);
-        wb.svis = static_cast<uint8_t*>(ctx->wsPtr[8]);
-        wb.camRays = static_cast<float4*>(ctx->wsPtr[9]);
+        wb.pathHead = static_cast<int32_t*>(ws[0]);
+        wb.pathCount = static_cast<uint8_t*>(ws[1]);
+        wb.pathBase = static_cast<uint32_t*>(ws[2]);
+        wb.pathEnv = static_cast<float*>(ws[3]);
+        wb.nodeA = static_cast<float4*>(ws[4]);
+        wb.nodeB = static_cast<NodeB*>(ws[5]);
+        wb.contrib = static_cast<float*>(ws[6]);
+        wb.srays = static_cast<float4*>(ws[7]);
+        wb.svis = static_cast<uint8_t*>(ws[8]);
+        wb.camRays = static_cast<float4*>(ws[9]);
         wb.maxNodes = static_cast<uint32_t>(maxNodes);
 
         for (uint64_t begin = 0; begin < fr.nWork; begin += batchSlots) {
             wp.slotBegin = static_cast<uint32_t>(begin);
             wp.nSlots = static_cast<uint32_t>(std::min<uint64_t>(batchSlots, fr.nWork - begin));
             if (begin != 0) // queue heads and the node allocator start over; the ray counters keep adding up
-                HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctx->dCounters) + offsetof(DevCounters, next), 0,
+                HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(dCounters) + offsetof(DevCounters, next), 0,
                     offsetof(DevCounters, loopIters) - offsetof(DevCounters, next), stream));
             // real pixels of the batch's tiles (edge tiles are padded to 8x8 slots)
             uint64_t validPixels = 0;
@@ -1281,7 +1446,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                 validPixels += static_cast<uint64_t>(std::min(kTile, width - tx * kTile)) * std::min(kTile, height - ty * kTile);
             }
             wp.validPaths = static_cast<uint32_t>(validPixels * wp.R);
-            const int pathBlocks = ctx->numCU * pathPerCU;
+            const int pathBlocks = pathBlocksAll;
             const int shadowBlocks = ctx->numCU * shadowPerCU;
             hipEvent_t* marks = nullptr;
             if (timeIt && ctx->marksUsed + 4 <= (1u << 18)) { // (beyond that many unread batches, only the frame is timed)
@@ -1295,12 +1460,12 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                 ctx->marksUsed += 4;
             }
             HIP_TRY(ctx, launchWavefront(dof, collect, transp, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
-                              wb, ctx->dCounters, dOut, traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB),
+                              wb, dCounters, dOut, traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB),
                               traceKnobs(ctx->minActiveShadow, ctx->parkAShadow, ctx->parkBShadow), marks, ctx->numCU));
         }
     }
     if (nShard == 1) { // a shard has no neighbours: a sharded frame is post-processed after its gather (rt_postprocess_device)
-        const int rb = bloomDevice(ctx, dOut, width, height, stream);
+        const int rb = bloomDevice(ctx, dOut, width, height, stream, bloomCopy);
         if (rb != RT_OK)
             return rb;
     }
@@ -1317,7 +1482,7 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
         ctx->hostCounters.reset(new DevCounters());
     DevCounters& c = *ctx->hostCounters;
     const bool debug = getenv("RT_AMD_DEBUG_COUNTERS") != nullptr;
-    HIP_TRY(ctx, hipMemcpy(&c, ctx->dCounters, debug ? sizeof c : offsetof(DevCounters, waveLog), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&c, ctx->lastCounters, debug ? sizeof c : offsetof(DevCounters, waveLog), hipMemcpyDeviceToHost));
     if (getenv("RT_AMD_DEBUG_COUNTERS") && (c.loopIters[0][2] | c.loopIters[1][2])) {
         // wave iterations of the traversal loop and the mean number of lanes that had work in them
         const char* names[2] = { "path", "shadow" };
@@ -1450,6 +1615,21 @@ try {
     return RT_OK;
 } catch (...) {
     return caught(ctx, "rt_render_device");
+}
+
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_camera* camera, int width, int height, int shard_index, int shard_count,
+    void* d_out, size_t d_out_floats, void* stream)
+try {
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_render_device_noalloc: ctx is NULL");
+    if (!ctx->scratchPtr)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: no scratch on device %d (ordinals up to %d)", ctx->device, kMaxDevices - 1);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Arena arena { static_cast<char*>(ctx->scratchPtr), kScratchBytes, 0 };
+    return renderCommon(ctx, camera, width, height, shard_index, shard_count, static_cast<float*>(d_out), d_out_floats,
+        static_cast<hipStream_t>(stream), false, false, &arena);
+} catch (...) {
+    return caught(ctx, "rt_render_device_noalloc");
 }
 
 int rt_postprocess_device(rt_ctx* ctx, void* d_frame, int width, int height, void* stream)

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
     const uint32_t total = ctr->camQueued.v;
     // node slots a wave reserves per atomic: about what its share of the rays will fill, so that a small
     // frame does not leave most of the pool's touched part empty (every slot is a work item further on)
-    uint32_t nodeBlock = kNodeBlock;
+    uint32_t nodeBlock = wp.nodeBlockMax;
     while (wp.nodeBlockFixed == 0u && nodeBlock > 64u && nodeBlock * (gridDim.x * (blockDim.x / 64u)) > 2u * total)
         nodeBlock >>= 1;
 

@@ -53,7 +53,8 @@ struct WfParams {
     uint32_t chunk;      // shadow rays per queue fetch, at most
     uint32_t chunkPath;  // camera rays per queue fetch, at most
     uint32_t leastPath;  // and at least (small frames)
-    uint32_t nodeBlockFixed; // experiments: 1 = node blocks of kNodeBlock slots whatever the frame's size
+    uint32_t nodeBlockFixed; // experiments: 1 = node blocks of nodeBlockMax slots whatever the frame's size
+    uint32_t nodeBlockMax;   // node slots a wavefront reserves at a time, at most (64 <= power of two <= kNodeBlock)
     uint32_t ownShare;   // sixteenths of a queue that its waves split up by position instead of fetching
     uint32_t validPaths; // camera rays of the batch's real (non-padding) pixels
 };
