@@ -743,6 +743,65 @@ def test_cpp_host_mirror():
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def _center_ray_hits(ctx, cam, w, h):
+    """Primitive index and t of the ray through every pixel's centre, in Screen order (device)."""
+    ys, xs = np.mgrid[0:h, 0:w]
+    yy = (h - 1 - ys).astype(np.float32)  # Screen order: row r holds y = h-1-r (src/screen.cpp:36-42)
+    ndc = np.stack([(xs.astype(np.float32) + np.float32(0.5)) / np.float32(w) * np.float32(2) - np.float32(1),
+                    (yy + np.float32(0.5)) / np.float32(h) * np.float32(2) - np.float32(1)], axis=-1).reshape(-1, 2)
+    r, hits = ctx.intersect(orc.generate_rays(cam, ndc))
+    return hits["primitive"].reshape(h, w), r["t"].reshape(h, w)
+
+
+@pytest.mark.parametrize("workload,distance", [("cornell", 3.0), ("teapot", 3.0), ("teapot", 1.6), ("monkey", 3.0), ("cube", 3.0),
+                                               ("dragon", 3.0)])
+def test_baseline_configurations_at_their_full_size_match_the_oracle(ctx, workload, distance):
+    """BASELINE configurations 1-4 at the sizes they are quoted on (512x512; 1920x1080; the dragon
+    stand-in at 1920x1080 with 16 pixel samples, the area light and mirror depth 4: 68.6 M rays, some
+    ten seconds of the CPU oracle on all host cores): renderImage (src/render.cpp:19-51) on the
+    device against the oracle on the same scene, camera and sampler seeds.  Ray counts equal, every
+    pixel within the stated tolerance (max-abs 2e-5, RMSE 2e-6), the primitive hit by the ray through
+    a pixel's centre the same on at least 99.9 % of the pixels."""
+    import bench
+    scn, f, w, h, _ = bench.build_workload(workload)
+    cam = sio.default_camera(w, h, distance=distance)
+    osc = _both(ctx, scn)
+    ctx.set_features(f)
+    img, st = ctx.render(cam, w, h)
+    ref, st_o = osc.render(f, cam, w, h)
+    maxabs, rmse = common.image_error(img, ref)
+    prim_o, t_o = osc.primary_hits(f, cam, w, h)
+    prim_g, t_g = _center_ray_hits(ctx, cam, w, h)
+    agree = float((prim_g == prim_o).mean())
+    exact = float((img.view(np.uint32) == ref.view(np.uint32)).mean())
+    print(f"{workload} {w}x{h} camera at {distance}: {st['rays']} rays (oracle {st_o['rays']}), maxabs {maxabs:.3g} rmse {rmse:.3g}, "
+          f"floats equal {exact:.6f}, centre-ray primitives equal {agree:.6f}")
+    assert st["rays"] == st_o["rays"]
+    assert maxabs <= 2e-5 and rmse <= 2e-6
+    assert agree >= 0.999
+    assert ref.any() and (prim_o >= 0).sum() > 1000
+    if workload == "dragon":
+        assert st["rays"] > 60_000_000
+
+
+def test_largest_configurations_features_match_the_oracle(ctx):
+    """BASELINE configuration 5's own feature set -- 64 pixel samples x 5 lens samples = 320 camera rays
+    per pixel, the area light x 4, transparency 0.6, mirror depth 4 -- at 240x136 (the 3840x2160 frame
+    is 47 G rays, hours of the CPU oracle): ray counts equal (186.6 M), pixels within the tolerance."""
+    import bench
+    scn, f, _, _, _ = bench.build_workload("dragon4k")
+    w, h = 240, 136
+    cam = sio.default_camera(w, h)
+    osc = _both(ctx, scn)
+    ctx.set_features(f)
+    img, st = ctx.render(cam, w, h)
+    ref, st_o = osc.render(f, cam, w, h)
+    maxabs, rmse = common.image_error(img, ref)
+    print(f"dragon4k features at {w}x{h}: {st['rays']} rays (oracle {st_o['rays']}), maxabs {maxabs:.3g} rmse {rmse:.3g}")
+    assert st["rays"] == st_o["rays"] and st["rays"] > 100_000_000
+    assert maxabs <= 2e-5 and rmse <= 2e-6 and ref.any()
+
+
 def _ctx_with_env(**env):  # (defined below the tests that use it; resolved at call time)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update({k: str(v) for k, v in env.items()})
