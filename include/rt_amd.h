@@ -10,7 +10,13 @@
  * Conventions: every call returns 0 on success and a negative rt_status on
  * failure; rt_last_error() returns the message of the last failure on that
  * context (or of the last context-less failure when ctx is NULL).  Calls on
- * one context must be serialised by the caller; one context drives one GPU.
+ * one context must be serialised by the caller; one context drives one GPU
+ * and carries the work of ONE stream at a time: its lights, counters and
+ * working memory are shared by the frames enqueued through it, which the
+ * order of a single stream keeps apart (lights re-sent between two frames
+ * reach the device in that stream's order, behind the earlier frame).  Frames
+ * meant to overlap -- several in flight on several streams -- take one
+ * context each (bench.py does that).
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H
@@ -177,6 +183,27 @@ typedef struct rt_ctx rt_ctx;
  * single-process CPU program); it owns what `Scene`/`BVH` own there. */
 int rt_ctx_create(int device_ordinal, rt_ctx** out);
 void rt_ctx_destroy(rt_ctx* ctx);
+
+/* Behaviour of a context that the reference has no notion of (no reference counterpart).
+ *  RT_OPT_TREE              which hierarchy the rays are walked through, from the next rt_scene_upload on:
+ *                           2 (default) the library's own over single primitives, 1 its own over the
+ *                           caller's leaves, 0 the caller's inner nodes as they are.  Results do not depend on it.
+ *  RT_OPT_PER_PIXEL         1 = every frame on the kernel that walks a pixel in renderRay's own depth-first
+ *                           order (the only one for glossy reflections); 0 (default) = queue-based renderer.
+ *  RT_OPT_STRICT_INTERSECT  1 = rt_intersect_batch replays every ray in the reference's own order of box
+ *                           and triangle tests (src/bvh.cpp:245-316), also reproducing the hits the
+ *                           reference's box routine loses by rounding for rays aimed exactly at vertices.
+ *  RT_OPT_WORKSPACE_BYTES   cap on the working memory of the queue-based renderer (default 64 GiB, never more
+ *                           than the device has free); a frame that needs more is rendered in pixel batches.
+ *  RT_OPT_TIMING            0 = record no events around the render launches (rt_stats times read 0). */
+enum rt_option {
+    RT_OPT_TREE = 1,
+    RT_OPT_PER_PIXEL = 2,
+    RT_OPT_STRICT_INTERSECT = 3,
+    RT_OPT_WORKSPACE_BYTES = 4,
+    RT_OPT_TIMING = 5
+};
+int rt_ctx_set_option(rt_ctx* ctx, int option, int64_t value);
 const char* rt_last_error(const rt_ctx* ctx);
 
 /* BVH::BVH(scene, features), src/bvh.cpp:52-101 with buildRecursive

@@ -18,7 +18,7 @@ EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_bvh_build", "rt_scene_upload", "rt_lights_set",
     "rt_features_set", "rt_render", "rt_render_device", "rt_shard_floats", "rt_deinterleave", "rt_sync",
     "rt_intersect_batch", "rt_eval_batch", "rt_postprocess_device", "rt_pack_bmp_device", "rt_bmp_header", "rt_write_bmp",
-    "rt_render_device_noalloc",
+    "rt_render_device_noalloc", "rt_ctx_set_option",
 ]
 
 (EVAL_BARYCENTRIC, EVAL_INTERP_NORMAL, EVAL_INTERP_TEXCOORD, EVAL_TEX_NEAREST, EVAL_TEX_BILINEAR,
@@ -103,16 +103,24 @@ def shard_floats(width, height, shard, n_shard) -> int:
     return int(lib().rt_shard_floats(width, height, shard, n_shard))
 
 
-class Context:
-    """One rt_ctx on one HIP device."""
+OPTIONS = {"tree": 1, "per_pixel": 2, "strict_intersect": 3, "workspace_bytes": 4, "timing": 5}  # enum rt_option
 
-    def __init__(self, device: int = 0):
+
+class Context:
+    """One rt_ctx on one HIP device; keyword arguments are rt_ctx_set_option settings (OPTIONS)."""
+
+    def __init__(self, device: int = 0, **options):
         self.handle = C.c_void_p()
         rc = lib().rt_ctx_create(int(device), C.byref(self.handle))
         if rc != 0:
             raise RtError(rc, lib().rt_last_error(None).decode())
         self.nodes = self.prims = None
         self.num_levels = self.num_leaves = 0
+        for name, value in options.items():
+            self.set_option(name, value)
+
+    def set_option(self, name: str, value: int):
+        self._check(lib().rt_ctx_set_option(self.handle, int(OPTIONS[name]), C.c_int64(int(value))))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -128,6 +128,7 @@ struct rt_ctx {
     rt_light* dLights = nullptr;
     uint32_t lightCap = 0;
     std::vector<rt_light> hostLights;
+    bool lightsDirty = false; // hostLights not yet copied to dLights
     bool anyMirror = true, anyClear = true, anyMirrorAndClear = true; // what the scene's materials can ask of a hit
     DevCounters* dCounters = nullptr;
     float* dFrame = nullptr;
@@ -140,6 +141,10 @@ struct rt_ctx {
     std::unique_ptr<DevCounters> hostCounters; // where readStats copies the device counters to
     std::vector<hipEvent_t> evPool, markPool;
     size_t evUsed = 0, marksUsed = 0;
+    // what the events recorded so far have been folded into (foldTimings), until the next stats read
+    double sumKernelMs = 0.0, sumPathMs = 0.0, sumShadowMs = 0.0;
+    uint64_t sumLaunches = 0, sumBatches = 0;
+    bool timing = true; // RT_OPT_TIMING: record events around the render launches
     DevScene scene {};
     bool haveScene = false;
     uint32_t numLevels = 1;
@@ -165,9 +170,9 @@ struct rt_ctx {
     // 2 = own SAH hierarchy over the caller's primitives, each a leaf of its own under its own box
     int treeMode = 2;
     size_t workspaceCap = 64ull << 30; // bytes the wavefront path may hold
-    // wavefront workspace (grow-only)
-    void* wsPtr[10] = {};
-    size_t wsBytes[10] = {};
+    // working memory of the queue-based path (one allocation, grow-only)
+    void* wsBase = nullptr;
+    size_t wsBytes = 0;
     // this device's copy of the static scratch array (rt_render_device_noalloc); null on a device
     // ordinal beyond the table
     void* scratchPtr = nullptr;
@@ -225,6 +230,41 @@ static int caught(rt_ctx* ctx, const char* where) noexcept
 
 static int warmOccupancy(rt_ctx* ctx);
 
+constexpr size_t kMaxTimedLaunches = 4096; // event pairs (and batch quadruples) kept before they are folded into sums
+
+// Adds the elapsed times between the events recorded so far to the context's running sums and
+// hands the events back for reuse.  The work they bracket must have finished.
+static int foldTimings(rt_ctx* ctx)
+{
+    for (size_t i = 0; i + 1 < ctx->evUsed; i += 2) {
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]));
+        ctx->sumKernelMs += ms;
+        ctx->sumLaunches++;
+    }
+    for (size_t i = 0; i + 3 < ctx->marksUsed; i += 4) {
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->markPool[i], ctx->markPool[i + 1]));
+        ctx->sumPathMs += ms;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->markPool[i + 2], ctx->markPool[i + 3]));
+        ctx->sumShadowMs += ms;
+        ctx->sumBatches++;
+    }
+    ctx->evUsed = ctx->marksUsed = 0;
+    return RT_OK;
+}
+
+// The lights last set, copied to the device in the order of `stream` (no-op when they are there already).
+static int flushLights(rt_ctx* ctx, hipStream_t stream)
+{
+    if (!ctx->lightsDirty)
+        return RT_OK;
+    if (!ctx->hostLights.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dLights, ctx->hostLights.data(), ctx->hostLights.size() * sizeof(rt_light), hipMemcpyHostToDevice, stream));
+    ctx->lightsDirty = false;
+    return RT_OK;
+}
+
 template <typename T>
 static hipError_t uploadVec(T** dptr, const std::vector<T>& v)
 {
@@ -239,6 +279,45 @@ static hipError_t uploadVec(T** dptr, const std::vector<T>& v)
     if (!v.empty())
         e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     return e;
+}
+
+// Scheduling parameters of the traversing kernels, overridable from the environment for the sweeps under
+// tools/ (only when RT_AMD_EXPERIMENTS is set).  What changes results or is of use to a caller is an
+// rt_option instead.
+static void readExperimentKnobs(rt_ctx* ctx)
+{
+    struct Knob {
+        const char* name;
+        int* a;
+        int* b; // second field set to the same value, or null
+        int lo, hi;
+    };
+    const Knob knobs[] = {
+        { "RT_AMD_MIN_ACTIVE", &ctx->minActive, &ctx->minActiveShadow, 0, 64 },
+        { "RT_AMD_MIN_ACTIVE_SHADOW", &ctx->minActiveShadow, nullptr, 0, 64 },
+        { "RT_AMD_PARK_A", &ctx->parkA, &ctx->parkAShadow, 0, 255 },
+        { "RT_AMD_PARK_B", &ctx->parkB, &ctx->parkBShadow, 0, 255 },
+        { "RT_AMD_PARK_A_SHADOW", &ctx->parkAShadow, nullptr, 0, 255 },
+        { "RT_AMD_PARK_B_SHADOW", &ctx->parkBShadow, nullptr, 0, 255 },
+        { "RT_AMD_CHUNK_PATH", &ctx->chunkPath, nullptr, 64, 1 << 20 },
+        { "RT_AMD_CHUNK_SHADOW", &ctx->chunkShadow, nullptr, 64, 1 << 20 },
+        { "RT_AMD_NODE_BLOCK_FIXED", &ctx->nodeBlockFixed, nullptr, 0, 1 },
+        { "RT_AMD_LEAST_PATH", &ctx->leastPath, nullptr, 1, 64 },
+        { "RT_AMD_OWN_SHARE", &ctx->ownShare, nullptr, 0, 16 },
+        { "RT_AMD_LOGIC_ROUNDS", &ctx->logicRounds, nullptr, 1, 64 },
+        { "RT_AMD_BLOCKS_PER_CU", &ctx->blocksPerCU, nullptr, 0, 32 },
+        { "RT_AMD_PATH_BLOCKS_PER_CU", &ctx->pathBlocksPerCU, nullptr, -1, 32 },
+        { "RT_AMD_SHADOW_BLOCKS_PER_CU", &ctx->shadowBlocksPerCU, nullptr, 0, 32 },
+        { "RT_AMD_FORCE_PATH_PER_CU", &ctx->forcePathPerCU, nullptr, 0, 32 },
+        { "RT_AMD_FORCE_SHADOW_PER_CU", &ctx->forceShadowPerCU, nullptr, 0, 32 },
+    };
+    for (const Knob& k : knobs)
+        if (const char* s = getenv(k.name)) {
+            const int v = std::min(k.hi, std::max(k.lo, atoi(s)));
+            *k.a = v;
+            if (k.b)
+                *k.b = v;
+        }
 }
 
 extern "C" {
@@ -273,52 +352,44 @@ try {
             return fail(nullptr, RT_ERR_DEVICE, "rt_ctx_create: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e));
         }
     }
-    if (const char* s = getenv("RT_AMD_MIN_ACTIVE"))
-        ctx->minActive = ctx->minActiveShadow = atoi(s);
-    if (const char* s = getenv("RT_AMD_MIN_ACTIVE_SHADOW"))
-        ctx->minActiveShadow = atoi(s);
-    if (const char* s = getenv("RT_AMD_PARK_A"))
-        ctx->parkA = ctx->parkAShadow = atoi(s);
-    if (const char* s = getenv("RT_AMD_PARK_B"))
-        ctx->parkB = ctx->parkBShadow = atoi(s);
-    if (const char* s = getenv("RT_AMD_PARK_A_SHADOW"))
-        ctx->parkAShadow = atoi(s);
-    if (const char* s = getenv("RT_AMD_PARK_B_SHADOW"))
-        ctx->parkBShadow = atoi(s);
-    if (const char* s = getenv("RT_AMD_CHUNK_PATH"))
-        ctx->chunkPath = std::max(64, atoi(s));
-    if (getenv("RT_AMD_NODE_BLOCK_FIXED"))
-        ctx->nodeBlockFixed = 1;
-    if (const char* s = getenv("RT_AMD_LEAST_PATH"))
-        ctx->leastPath = std::min(64, std::max(1, atoi(s)));
-    if (const char* s = getenv("RT_AMD_OWN_SHARE"))
-        ctx->ownShare = std::min(16, std::max(0, atoi(s)));
-    if (const char* s = getenv("RT_AMD_CHUNK_SHADOW"))
-        ctx->chunkShadow = std::max(64, atoi(s));
-    if (const char* s = getenv("RT_AMD_LOGIC_ROUNDS"))
-        ctx->logicRounds = std::max(1, atoi(s));
-    if (const char* s = getenv("RT_AMD_BLOCKS_PER_CU"))
-        ctx->blocksPerCU = atoi(s);
-    if (const char* s = getenv("RT_AMD_FORCE_PATH_PER_CU"))
-        ctx->forcePathPerCU = atoi(s);
-    if (const char* s = getenv("RT_AMD_FORCE_SHADOW_PER_CU"))
-        ctx->forceShadowPerCU = atoi(s);
-    if (const char* s = getenv("RT_AMD_SHADOW_BLOCKS_PER_CU"))
-        ctx->shadowBlocksPerCU = atoi(s);
-    if (const char* s = getenv("RT_AMD_PATH_BLOCKS_PER_CU"))
-        ctx->pathBlocksPerCU = atoi(s);
-    if (const char* s = getenv("RT_AMD_STRICT_INTERSECT"))
-        ctx->strictIntersect = atoi(s) != 0;
-    if (const char* s = getenv("RT_AMD_TREE"))
-        ctx->treeMode = atoi(s);
-    if (const char* s = getenv("RT_AMD_PER_PIXEL"))
-        ctx->forcePerPixel = atoi(s);
-    if (const char* s = getenv("RT_AMD_WORKSPACE_GB"))
-        ctx->workspaceCap = static_cast<size_t>(std::max(1.0, atof(s) * 1024.0)) << 20; // fractions allowed, at least 1 MiB
+    if (getenv("RT_AMD_EXPERIMENTS")) // scheduling experiments (tools/*.sh); nothing a caller needs
+        readExperimentKnobs(ctx);
     *out = ctx;
     return RT_OK;
 } catch (...) {
     return caught(nullptr, "rt_ctx_create");
+}
+
+int rt_ctx_set_option(rt_ctx* ctx, int option, int64_t value)
+try {
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_ctx_set_option: ctx is NULL");
+    switch (option) {
+    case RT_OPT_TREE:
+        if (value < 0 || value > 2)
+            return fail(ctx, RT_ERR_INVALID, "rt_ctx_set_option: RT_OPT_TREE takes 0, 1 or 2");
+        ctx->treeMode = static_cast<int>(value);
+        return RT_OK;
+    case RT_OPT_PER_PIXEL:
+        ctx->forcePerPixel = value != 0;
+        return RT_OK;
+    case RT_OPT_STRICT_INTERSECT:
+        ctx->strictIntersect = value != 0;
+        ctx->scene.strictIntersect = ctx->strictIntersect ? 1 : 0;
+        return RT_OK;
+    case RT_OPT_WORKSPACE_BYTES:
+        if (value < (1 << 20))
+            return fail(ctx, RT_ERR_INVALID, "rt_ctx_set_option: RT_OPT_WORKSPACE_BYTES takes at least 1 MiB");
+        ctx->workspaceCap = static_cast<size_t>(value);
+        return RT_OK;
+    case RT_OPT_TIMING:
+        ctx->timing = value != 0;
+        return RT_OK;
+    default:
+        return fail(ctx, RT_ERR_INVALID, "rt_ctx_set_option: unknown option %d", option);
+    }
+} catch (...) {
+    return caught(ctx, "rt_ctx_set_option");
 }
 
 void rt_ctx_destroy(rt_ctx* ctx)
@@ -332,9 +403,8 @@ void rt_ctx_destroy(rt_ctx* ctx)
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
-    for (void* p : ctx->wsPtr)
-        if (p)
-            (void)hipFree(p);
+    if (ctx->wsBase)
+        (void)hipFree(ctx->wsBase);
     for (hipEvent_t e : ctx->markPool)
         (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->evPool)
@@ -1003,9 +1073,10 @@ try {
         ctx->lightCap = std::max<uint32_t>(n, 16);
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->dLights), ctx->lightCap * sizeof(rt_light)));
     }
-    if (n)
-        HIP_TRY(ctx, hipMemcpy(ctx->dLights, lights, n * sizeof(rt_light), hipMemcpyHostToDevice));
+    // The lights reach the device with the next call that reads them, as a copy enqueued on that call's
+    // own stream: frames already enqueued there keep the lights they were enqueued with.
     ctx->hostLights.assign(lights, lights + n);
+    ctx->lightsDirty = true;
     ctx->scene.lights = ctx->dLights;
     ctx->scene.nLights = static_cast<int32_t>(n);
     return RT_OK;
@@ -1247,12 +1318,19 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             return fail(ctx, RT_ERR_INTERNAL, "render: scratch smaller than the counters");
     }
     ctx->lastCounters = dCounters;
+    {
+        const int rl = flushLights(ctx, stream);
+        if (rl != RT_OK)
+            return rl;
+    }
     HIP_TRY(ctx, hipMemsetAsync(dCounters, 0, collect ? sizeof(DevCounters) : offsetof(DevCounters, waveLog), stream));
     if (timeIt) {
         if (ctx->evUsed + 2 > ctx->evPool.size()) {
-            if (ctx->evPool.size() >= 2 * 4096) { // unread launches pile up: fold them by waiting once
+            if (ctx->evPool.size() >= 2 * kMaxTimedLaunches) { // unread launches pile up: wait once and fold them into the sums
                 HIP_TRY(ctx, hipStreamSynchronize(stream));
-                ctx->evUsed = ctx->marksUsed = 0;
+                const int rf = foldTimings(ctx);
+                if (rf != RT_OK)
+                    return rf;
             } else {
                 for (int i = 0; i < 2; i++) {
                     hipEvent_t a;
@@ -1377,47 +1455,75 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * nodesPerPath;
         const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + 32 + (F.enableEnvironmentMap ? 12 : 0))
             + nodesPerPixel * perNodeBytes;
-        // (the context's own buffers are virtual memory that is only touched where hits exist; an arena
-        // is real: the unused ends of the node blocks and the buffers' alignment come out of it first)
-        const uint64_t fixedBytes = arena ? nodeSlack * perNodeBytes + 16 * 256 : 0;
-        uint64_t batchSlots = (workspaceCap > fixedBytes ? workspaceCap - fixedBytes : 0) / std::max<uint64_t>(1, bytesPerPixel);
-        batchSlots = std::min<uint64_t>(batchSlots, 0x7fffffffull / wp.R);                                       // path index in 31 bits
+        // what does not shrink with the batch: the unused ends of the node blocks, the buffers' alignment
+        const uint64_t fixedBytes = nodeSlack * perNodeBytes + 16 * 256;
         // item index (node * slots + slot) in 32 bits, with room for the queue head to run past the end
         // by one batch per wavefront
         const uint64_t nodeCap = (0xffffffffull - (1ull << 26)) / std::max(1u, slots);
         if (nodeCap <= nodeSlack)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u light samples per hit exceed the supported count", slots);
-        batchSlots = std::min<uint64_t>(batchSlots, (nodeCap - nodeSlack) / nodesPerPixel);
-        batchSlots = std::min<uint64_t>(batchSlots, fr.nWork) & ~63ull;
+        // pixel slots (whole tiles) of one batch under a cap on the working memory
+        auto slotsUnder = [&](uint64_t cap, uint64_t fixed) {
+            uint64_t n = (cap > fixed ? cap - fixed : 0) / std::max<uint64_t>(1, bytesPerPixel);
+            n = std::min<uint64_t>(n, 0x7fffffffull / wp.R); // path index in 31 bits
+            n = std::min<uint64_t>(n, (nodeCap - nodeSlack) / nodesPerPixel);
+            return std::min<uint64_t>(n, fr.nWork) & ~63ull;
+        };
+        size_t want[10];
+        uint64_t maxNodes = 0;
+        auto sizesFor = [&](uint64_t batch) { // the ten buffers of a batch of that many pixel slots; returns their sum
+            const uint64_t paths = batch * wp.R;
+            maxNodes = batch * nodesPerPixel + nodeSlack;
+            const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, slots);
+            const size_t w[10] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
+                F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
+                static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * (transp ? 48 : 32), transp ? items : 16,
+                static_cast<size_t>(paths) * 32 };
+            size_t total = 0;
+            for (int i = 0; i < 10; i++)
+                want[i] = w[i], total += (w[i] + 255) & ~size_t(255);
+            return total;
+        };
+        // (RT_OPT_WORKSPACE_BYTES caps what grows with the batch; memory that is really there -- an arena, or
+        // what the device has free, below -- has to hold the fixed part as well)
+        uint64_t batchSlots = slotsUnder(workspaceCap, arena ? fixedBytes : 0);
         if (batchSlots == 0)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: one 8x8 tile of this frame needs %llu bytes of working memory, more than the %zu-byte %s",
                 static_cast<unsigned long long>(64 * bytesPerPixel + fixedBytes), workspaceCap, arena ? "scratch left" : "workspace");
-        const uint64_t paths = batchSlots * wp.R, maxNodes = batchSlots * nodesPerPixel + nodeSlack;
-        const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, slots);
-        const size_t want[10] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
-            F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
-            static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * (transp ? 48 : 32), transp ? items : 16, static_cast<size_t>(paths) * 32 };
-        void* ws[10];
-        if (arena) {
-            for (int i = 0; i < 10; i++) {
-                ws[i] = arena->take(want[i]);
-                if (!ws[i])
-                    return fail(ctx, RT_ERR_INTERNAL, "render: working buffers exceed the scratch (%zu of %zu bytes used, %zu more asked)",
-                        arena->used, arena->bytes, want[i]);
-            }
-        } else {
-            for (int i = 0; i < 10; i++) {
-                if (ctx->wsBytes[i] < want[i]) {
-                    HIP_TRY(ctx, hipStreamSynchronize(stream));
-                    if (ctx->wsPtr[i])
-                        (void)hipFree(ctx->wsPtr[i]);
-                    ctx->wsPtr[i] = nullptr;
-                    ctx->wsBytes[i] = 0;
-                    HIP_TRY(ctx, hipMalloc(&ctx->wsPtr[i], want[i]));
-                    ctx->wsBytes[i] = want[i];
+        size_t total = sizesFor(batchSlots);
+        Arena own { nullptr, 0, 0 };
+        if (!arena) {
+            // The context's own working memory: one allocation, grown when a frame asks for more.  All sizes are
+            // known before anything is freed, and a frame never asks for more than the device has left
+            // (with what the context already holds): it is rendered in more pixel batches instead.
+            if (total > ctx->wsBytes) {
+                size_t freeB = 0, totalB = 0;
+                HIP_TRY(ctx, hipMemGetInfo(&freeB, &totalB));
+                const size_t allowed = ctx->wsBytes + freeB - freeB / 8;
+                if (total > allowed) {
+                    batchSlots = slotsUnder(allowed, fixedBytes);
+                    if (batchSlots == 0)
+                        return fail(ctx, RT_ERR_DEVICE, "render: %zu bytes of device memory are free, one 8x8 tile of this frame needs %llu",
+                            freeB, static_cast<unsigned long long>(64 * bytesPerPixel + fixedBytes));
+                    total = sizesFor(batchSlots);
                 }
-                ws[i] = ctx->wsPtr[i];
+                HIP_TRY(ctx, hipStreamSynchronize(stream)); // (frames still in flight on this stream use the old buffer)
+                if (ctx->wsBase)
+                    (void)hipFree(ctx->wsBase);
+                ctx->wsBase = nullptr;
+                ctx->wsBytes = 0;
+                HIP_TRY(ctx, hipMalloc(&ctx->wsBase, total));
+                ctx->wsBytes = total;
             }
+            own = Arena { static_cast<char*>(ctx->wsBase), ctx->wsBytes, 0 };
+            arena = &own;
+        }
+        void* ws[10];
+        for (int i = 0; i < 10; i++) {
+            ws[i] = arena->take(want[i]);
+            if (!ws[i])
+                return fail(ctx, RT_ERR_INTERNAL, "render: working buffers exceed their memory (%zu of %zu bytes used, %zu more asked)",
+                    arena->used, arena->bytes, want[i]);
         }
         WfBuffers wb {};
         wb.pathHead = static_cast<int32_t*>(ws[0]);
@@ -1449,7 +1555,17 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             const int pathBlocks = pathBlocksAll;
             const int shadowBlocks = ctx->numCU * shadowPerCU;
             hipEvent_t* marks = nullptr;
-            if (timeIt && ctx->marksUsed + 4 <= (1u << 18)) { // (beyond that many unread batches, only the frame is timed)
+            if (timeIt && ctx->marksUsed + 4 > 4 * kMaxTimedLaunches) { // a frame of very many batches, or many unread frames
+                HIP_TRY(ctx, hipStreamSynchronize(stream));
+                // this frame's own start event sits at evPool[evUsed], behind the finished pairs: those and the
+                // batches so far are folded, the start event moves to the front of the emptied pool
+                const size_t open = ctx->evUsed;
+                const int rf = foldTimings(ctx);
+                if (rf != RT_OK)
+                    return rf;
+                std::swap(ctx->evPool[0], ctx->evPool[open]);
+            }
+            if (timeIt) {
                 while (ctx->markPool.size() < ctx->marksUsed + 4) {
                     hipEvent_t a;
                     HIP_TRY(ctx, hipEventCreate(&a));
@@ -1519,6 +1635,11 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
                 li > 0 ? c.topHits[k][0] / li : 0.0, li > 0 ? c.topHits[k][1] / li : 0.0, li > 0 ? c.topHits[k][2] / li : 0.0, ctx->numLevels);
         }
     }
+    if (c.overflow) {
+        ctx->evUsed = ctx->marksUsed = 0;
+        return fail(ctx, RT_ERR_INTERNAL, "render: %llu hits found no slot in the hit pool (the frame is invalid; this is a bug in the pool's sizing)",
+            static_cast<unsigned long long>(c.overflow));
+    }
     if (stats) {
         stats->rays = c.rays;
         stats->inner_nodes = c.inner;
@@ -1529,20 +1650,16 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
         stats->kernel_ms = stats->path_ms = stats->shadow_ms = 0.0f;
         stats->launches = stats->batches = 0;
         if (timed) {
-            for (size_t i = 0; i + 1 < ctx->evUsed; i += 2) {
-                float ms = 0.0f;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[i], ctx->evPool[i + 1]));
-                stats->kernel_ms += ms;
-                stats->launches++;
-            }
-            for (size_t i = 0; i + 3 < ctx->marksUsed; i += 4) {
-                float ms = 0.0f;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->markPool[i], ctx->markPool[i + 1]));
-                stats->path_ms += ms;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->markPool[i + 2], ctx->markPool[i + 3]));
-                stats->shadow_ms += ms;
-                stats->batches++;
-            }
+            const int rf = foldTimings(ctx);
+            if (rf != RT_OK)
+                return rf;
+            stats->kernel_ms = static_cast<float>(ctx->sumKernelMs);
+            stats->path_ms = static_cast<float>(ctx->sumPathMs);
+            stats->shadow_ms = static_cast<float>(ctx->sumShadowMs);
+            stats->launches = static_cast<uint32_t>(ctx->sumLaunches);
+            stats->batches = static_cast<uint32_t>(ctx->sumBatches);
+            ctx->sumKernelMs = ctx->sumPathMs = ctx->sumShadowMs = 0.0;
+            ctx->sumLaunches = ctx->sumBatches = 0;
         }
     }
     ctx->evUsed = ctx->marksUsed = 0;
@@ -1579,7 +1696,7 @@ try {
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->dFrame), floats * sizeof(float)));
         ctx->frameCap = floats;
     }
-    const int rc = renderCommon(ctx, camera, width, height, 0, 1, ctx->dFrame, floats, nullptr, false, true);
+    const int rc = renderCommon(ctx, camera, width, height, 0, 1, ctx->dFrame, floats, nullptr, false, ctx->timing || stats != nullptr);
     if (rc != RT_OK)
         return rc;
     HIP_TRY(ctx, hipMemcpy(out_rgb, ctx->dFrame, floats * sizeof(float), hipMemcpyDeviceToHost));
@@ -1601,7 +1718,7 @@ try {
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int rc = renderCommon(ctx, camera, width, height, shard_index, shard_count, static_cast<float*>(d_out), d_out_floats,
-        static_cast<hipStream_t>(stream), collect_stats != 0, true);
+        static_cast<hipStream_t>(stream), collect_stats != 0, ctx->timing || collect_stats != 0);
     if (rc != RT_OK)
         return rc;
     if (collect_stats) {
@@ -1842,6 +1959,11 @@ try {
         std::memset(&f, 0, sizeof f);
     const DevFeat ft = makeFeat(f);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        const int rl = flushLights(ctx, nullptr);
+        if (rl != RT_OK)
+            return rl;
+    }
     float *dIn = nullptr, *dOut = nullptr;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dIn), inFloats * sizeof(float)));
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&dOut), outFloats * sizeof(float));

@@ -141,7 +141,7 @@ struct DevScene {
     // upper, data[2]); only read when a ray has to be replayed in the reference's order of tests
     // (Tracer::settleTie).  Null when the caller's tree is deeper than a lane's stack.
     const uint4* refNodes;
-    // rt_intersect_batch only: replay every ray that way (RT_AMD_STRICT_INTERSECT=1).  The reference's own box
+    // rt_intersect_batch only: replay every ray that way (RT_OPT_STRICT_INTERSECT).  The reference's own box
     // test is not conservative: a ray aimed exactly at a vertex or at the corner of a leaf's box can
     // miss, by rounding, a box that holds its hit, and the reference then reports the next hit or none,
     // where the traversal here (whose box tests never lose a hit) reports the nearer one.
@@ -196,6 +196,7 @@ struct alignas(128) HotCounter {
 struct DevCounters {
     unsigned long long rays, inner, tris;       // accumulated over the frame, all kernels
     unsigned long long sRays, sInner, sTris;    // the shadow kernel's share of them
+    unsigned long long overflow;                // hits that found no slot in the pool (the host's bound was wrong: the frame is invalid)
     // work-queue heads, the node allocator, the number of queued camera rays, and the flags the first
     // wave to find a queue empty raises for the others ([0] path, [1] shadow); cleared before every batch
     HotCounter next, nextShadow, nodes, camQueued, dry[2];

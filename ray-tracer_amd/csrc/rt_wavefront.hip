@@ -396,6 +396,13 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
                                 depth++;
                             }
                         }
+                    } else {
+                        // The pool is sized for the worst case of the batch, so this cannot happen unless the
+                        // host's bound is wrong.  Then the frame is invalid and says so (rt_sync fails); the
+                        // hit is dropped in a way that leaves the records the later kernels follow consistent.
+                        if (depth == 0)
+                            wb.pathHead[path] = kPathMiss;
+                        atomicAdd(&ctr->overflow, 1ull);
                     }
                 }
                 if (!childLaunched) {

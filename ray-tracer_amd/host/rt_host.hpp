@@ -17,6 +17,9 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <random>
+#include <concepts>
+#include <type_traits>
 #include <span>
 #include <stdexcept>
 #include <string>
@@ -158,21 +161,49 @@ struct Features {
     ExtraFeatures extra = {};
 };
 
-// src/scene.h:29-49
+// src/scene.h:15-49
+enum SceneType { SingleTriangle, Cube, CubeTextured, CornellBox, CornellBoxTransparency, CornellBoxParallelogramLight, Monkey, Teapot, Dragon, Spheres, Custom };
 struct Scene {
     using SceneLight = std::variant<PointLight, SegmentLight, ParallelogramLight>;
+    SceneType type = Custom;
     std::vector<Mesh> meshes;
     std::vector<Sphere> spheres;
     std::vector<SceneLight> lights;
     std::shared_ptr<Image> environmentMapTextures[6];
 };
 
+// src/sampler.h:13-46: the generator behind every random draw of the path, for host code that
+// wants the same stream (the device seeds its own per pixel, src/render.cpp:38).
+class Sampler {
+public:
+    Sampler(uint32_t seed = std::random_device()()) : m_state(seed) {}
+    float next_1d()
+    {
+        m_state = m_state * 747796405u + 2891336453u;
+        uint32_t v = m_state;
+        v ^= v >> ((v >> 28u) + 4u);
+        v *= 277803737u;
+        v ^= v >> 22u;
+        return static_cast<float>(v) / 4294967295.f;
+    }
+    vec2 next_2d()
+    {
+        const float a = next_1d(); // (first draw is x: the reference's braced initialiser evaluates left to right)
+        const float b = next_1d();
+        return { a, b };
+    }
+
+private:
+    uint32_t m_state;
+};
+
 struct BVHInterface;
-// src/render.h:17-26 (the sampler lives on the device, seeded per pixel as src/render.cpp:38)
+// src/render.h:17-26
 struct RenderState {
     const Scene& scene;
     const Features& features;
     const BVHInterface& bvh;
+    Sampler sampler;
 };
 
 // The one rt_ctx of the process (device RT_AMD_DEVICE, default 0).  Failures of the
@@ -191,6 +222,15 @@ public:
             throw std::runtime_error(std::string(what) + ": " + rt_last_error(m_ctx));
     }
     uint64_t uploadedHash = 0;
+    // Releases the context now (a program that wants its device memory back, or that does not want
+    // the release to happen among the static destructors at exit, where the GPU runtime may be gone).
+    void shutdown()
+    {
+        if (m_ctx)
+            rt_ctx_destroy(m_ctx);
+        m_ctx = nullptr;
+        uploadedHash = 0;
+    }
 
 private:
     Device()
@@ -201,7 +241,7 @@ private:
         if (rt_ctx_create(dev, &m_ctx) != RT_OK)
             throw std::runtime_error(std::string("rt_ctx_create: ") + rt_last_error(nullptr));
     }
-    ~Device() { rt_ctx_destroy(m_ctx); }
+    ~Device() { shutdown(); }
     rt_ctx* m_ctx = nullptr;
 };
 
@@ -321,14 +361,24 @@ inline void syncScene(const Scene& scene, const BVHInterface& bvh, const Feature
     for (int i = 0; i < 6; i++)
         env[i] = imageIndex(scene.environmentMapTextures[i]);
 
+    // What is on the device is known by the identity of the large arrays (which BVH object, where its
+    // node and primitive arrays and the images' pixels live, how large they are) and by the content of
+    // the small tables (materials, spheres, environment faces): cheap enough for every frame.  A caller
+    // that rewrites nodes, primitives or texels in place says so with invalidateScene().
     uint64_t h = 1469598103934665603ull;
-    h = detail::fnv(nodes.data(), nodes.size_bytes(), h);
-    h = detail::fnv(prims.data(), prims.size_bytes(), h);
+    const void* ids[] = { &bvh, nodes.data(), prims.data() };
+    const size_t sizes[] = { nodes.size(), prims.size(), scene.meshes.size(), scene.spheres.size() };
+    h = detail::fnv(ids, sizeof ids, h);
+    h = detail::fnv(sizes, sizeof sizes, h);
     h = detail::fnv(mats.data(), mats.size() * sizeof(rt_material), h);
     h = detail::fnv(spheres.data(), spheres.size() * sizeof(rt_sphere), h);
     h = detail::fnv(env, sizeof env, h);
-    for (const rt_image& im : images)
-        h = detail::fnv(im.pixels, size_t(im.width) * im.height * 12, h);
+    for (const rt_image& im : images) {
+        h = detail::fnv(&im.pixels, sizeof im.pixels, h);
+        h = detail::fnv(&im.width, 2 * sizeof(int32_t), h);
+    }
+    if (h == 0)
+        h = 1; // 0 stands for "nothing uploaded"
     if (h != dev.uploadedHash) {
         dev.check(rt_scene_upload(dev.ctx(), reinterpret_cast<const rt_node*>(nodes.data()), static_cast<uint32_t>(nodes.size()),
                       reinterpret_cast<const rt_primitive*>(prims.data()), static_cast<uint32_t>(prims.size()), mats.data(),
@@ -358,6 +408,10 @@ inline void syncScene(const Scene& scene, const BVHInterface& bvh, const Feature
     const rt_features f = detail::toC(features);
     dev.check(rt_features_set(dev.ctx(), &f), "rt_features_set");
 }
+
+// The next renderImage / intersect uploads the scene again whatever it looks like (after writing
+// into nodes(), primitives() or an image's pixels in place).
+inline void invalidateScene() { Device::get().uploadedHash = 0; }
 
 // src/bvh.h:60-125
 struct BVH : public BVHInterface {
@@ -485,5 +539,69 @@ inline void renderImage(const Scene& scene, const BVHInterface& bvh, const Featu
     const ivec2 res = screen.resolution();
     dev.check(rt_render(dev.ctx(), &cam, res.x, res.y, reinterpret_cast<float*>(screen.pixels().data()), nullptr), "rt_render");
 }
+
+// The shape of the interface that code written against the reference relies on, as the
+// reference's src/verification.cpp:11-144 pins it: member names and exact member types of Scene,
+// RenderState, Features, BVHInterface and its Node / Primitive records, and BVH deriving from
+// BVHInterface.  A change to this header that breaks one of them does not compile.
+namespace contract {
+template <typename T, typename M>
+concept exactly = std::same_as<T, M>;
+
+template <typename S>
+concept scene_shape = requires(S s) {
+    { s.type } -> exactly<SceneType&>;
+    { s.meshes } -> exactly<std::vector<Mesh>&>;
+    { s.spheres } -> exactly<std::vector<Sphere>&>;
+    { s.lights } -> exactly<std::vector<typename S::SceneLight>&>;
+};
+template <typename R>
+concept render_state_shape = requires(R r) {
+    { r.scene } -> exactly<const Scene&>;
+    { r.features } -> exactly<const Features&>;
+    { r.bvh } -> exactly<const BVHInterface&>;
+    { r.sampler } -> exactly<Sampler&>;
+};
+template <typename F>
+concept features_shape = requires(F f) {
+    { f.enableShading } -> exactly<bool&>;
+    { f.enableReflections } -> exactly<bool&>;
+    { f.enableShadows } -> exactly<bool&>;
+    { f.enableNormalInterp } -> exactly<bool&>;
+    { f.enableTextureMapping } -> exactly<bool&>;
+    { f.enableAccelStructure } -> exactly<bool&>;
+    { f.enableBilinearTextureFiltering } -> exactly<bool&>;
+    { f.enableTransparency } -> exactly<bool&>;
+    { f.shadingModel } -> exactly<ShadingModel&>;
+    { f.numPixelSamples } -> exactly<uint32_t&>;
+    { f.numShadowSamples } -> exactly<uint32_t&>;
+    { f.extra } -> exactly<ExtraFeatures&>;
+};
+template <typename N>
+concept node_shape = requires(N n) {
+    { n.aabb } -> exactly<AxisAlignedBox&>;
+    { n.data } -> exactly<std::array<uint32_t, 2>&>;
+};
+template <typename P>
+concept primitive_shape = requires(P p) {
+    { p.meshID } -> exactly<uint32_t&>;
+    { p.v0 } -> exactly<Vertex&>;
+};
+template <typename B>
+concept bvh_interface_shape = requires(B b, RenderState& state, Ray& ray, HitInfo& hitInfo) {
+    { b.nodes() } -> exactly<std::span<BVHInterface::Node>>;
+    { b.primitives() } -> exactly<std::span<BVHInterface::Primitive>>;
+    { b.numLevels() } -> exactly<uint32_t>;
+    { b.numLeaves() } -> exactly<uint32_t>;
+    { b.intersect(state, ray, hitInfo) } -> exactly<bool>;
+};
+static_assert(scene_shape<Scene>, "Scene: type / meshes / spheres / lights");
+static_assert(render_state_shape<RenderState>, "RenderState: scene / features / bvh / sampler");
+static_assert(features_shape<Features>, "Features: the eight switches, shadingModel, sample counts, extra");
+static_assert(bvh_interface_shape<BVHInterface>, "BVHInterface: nodes / primitives / numLevels / numLeaves / intersect");
+static_assert(node_shape<BVHInterface::Node>, "BVHInterface::Node: aabb + data[2]");
+static_assert(primitive_shape<BVHInterface::Primitive>, "BVHInterface::Primitive: meshID + vertices");
+static_assert(std::is_base_of_v<BVHInterface, BVH>, "BVH implements BVHInterface");
+} // namespace contract
 
 } // namespace rthost

@@ -6,7 +6,7 @@
 #include <cstdlib>
 
 #include "../../oracle/rt_oracle.h"
-#include "rt_host.hpp"
+#include "../../ray-tracer_amd/host/rt_host.hpp"
 
 using namespace rthost;
 
@@ -175,10 +175,28 @@ static void renderAgainstOracle()
     CHECK(threw);
 }
 
+// src/sampler.h:16-45: the host-side Sampler draws the oracle's stream
+static void samplerStream()
+{
+    for (uint32_t seed : { 0u, 123u, 1080u * 700u + 3u, 0xffffffffu }) {
+        float want[64];
+        orc_sampler_next(seed, 64, want);
+        Sampler s(seed);
+        bool same = true;
+        for (int i = 0; i < 64; i += 2) {
+            const vec2 v = s.next_2d();
+            same = same && v.x == want[i] && v.y == want[i + 1];
+        }
+        CHECK(same);
+    }
+}
+
 int main()
 {
+    samplerStream();
     pyramidInsidePyramid();
     renderAgainstOracle();
+    Device::get().shutdown(); // not among the static destructors at exit
     std::printf("%d checks, %d failed\n", g_checks, g_failed);
     return g_failed ? 1 : 0;
 }

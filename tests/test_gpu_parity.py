@@ -239,8 +239,8 @@ def test_hundreds_of_camera_rays_per_pixel():
                             numDepthOfFieldSamples=lens, depthOfFieldDistance=2.5, maxRayDepth=2)
         ref, st_o = osc.render(f, cam, w, h)
         images = []
-        for env in (dict(RT_AMD_PER_PIXEL=0), dict(RT_AMD_PER_PIXEL=1)):
-            c = _ctx_with_env(**env)
+        for env in (dict(per_pixel=0), dict(per_pixel=1)):
+            c = _ctx_with(**env)
             c.upload_scene(scn)
             c.set_features(f)
             img, st = c.render(cam, w, h)
@@ -288,9 +288,9 @@ def test_primitives_met_at_the_same_distance():
                             enableEnvironmentMap=1, shadingModel=2, numPixelSamples=2, numShadowSamples=2, maxRayDepth=3)
         ref, st_o = osc.render(f, cam, w, h)
         r_o, h_o, _ = osc.intersect(f, rays)
-        for env in (dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=1, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=0, RT_AMD_PER_PIXEL=0),
-                    dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=1)):
-            c = _ctx_with_env(**env)
+        for env in (dict(tree=2, per_pixel=0), dict(tree=1, per_pixel=0), dict(tree=0, per_pixel=0),
+                    dict(tree=2, per_pixel=1)):
+            c = _ctx_with(**env)
             c.upload_scene(scn)
             c.set_features(f)
             img, st = c.render(cam, w, h)
@@ -311,8 +311,8 @@ def test_primitives_met_at_the_same_distance():
                         shadingModel=2, numPixelSamples=2, numShadowSamples=2, maxRayDepth=3)
     ref, st_o = osc.render(f, cam, w, h)
     r_o, h_o, _ = osc.intersect(f, rays)
-    for env in (dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=0, RT_AMD_PER_PIXEL=1)):
-        c = _ctx_with_env(**env)
+    for env in (dict(tree=2, per_pixel=0), dict(tree=0, per_pixel=1)):
+        c = _ctx_with(**env)
         c.upload_scene(scn, nodes, prims)
         c.set_features(f)
         img, st = c.render(cam, w, h)
@@ -345,8 +345,8 @@ def test_transparency_tree_matches_oracle_and_per_pixel_kernel():
                             enableEnvironmentMap=1, shadingModel=2, numPixelSamples=2, numShadowSamples=3, maxRayDepth=5)
         ref, st_o = osc.render(f, cam, w, h)
         images = []
-        for env in (dict(RT_AMD_PER_PIXEL=0), dict(RT_AMD_PER_PIXEL=0, RT_AMD_WORKSPACE_GB=0.004), dict(RT_AMD_PER_PIXEL=1)):
-            c = _ctx_with_env(**env)
+        for env in (dict(per_pixel=0), dict(per_pixel=0, workspace_bytes=4 << 20), dict(per_pixel=1)):
+            c = _ctx_with(**env)
             c.upload_scene(scn)
             c.set_features(f)
             img, st = c.render(cam, w, h)
@@ -467,9 +467,9 @@ def test_triangle_soup_with_degenerate_and_repeated_triangles():
     r_o, h_o, _ = osc.intersect(f_hit, rays)
     ref, st_o = osc.render(f_img, cam, w, h)
     assert 0.2 < h_o["hit"].mean() < 1.0 and ref.any()
-    for env in (dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=1, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=0, RT_AMD_PER_PIXEL=0),
-                dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=1)):
-        c = _ctx_with_env(**env)
+    for env in (dict(tree=2, per_pixel=0), dict(tree=1, per_pixel=0), dict(tree=0, per_pixel=0),
+                dict(tree=2, per_pixel=1)):
+        c = _ctx_with(**env)
         c.upload_scene(scn)
         c.set_features(f_hit)
         r_g, h_g = c.intersect(rays)
@@ -497,7 +497,7 @@ def test_rays_aimed_at_vertices_in_strict_mode():
     none.  The traversal never loses a hit, so on such rays it differs from the reference by design
     (half a per cent of such rays on the Cornell box, a tenth when many of them also run along an axis;
     none of the rays of the frames compared).  With
-    RT_AMD_STRICT_INTERSECT=1 rt_intersect_batch replays every ray in the reference's own order of tests
+    RT_OPT_STRICT_INTERSECT set, rt_intersect_batch replays every ray in the reference's own order of tests
     (the routine that settles equal-distance hits) and must agree on all of them."""
     scn = common.scene("CornellBox")
     osc = orc.OracleScene(scn)
@@ -514,7 +514,7 @@ def test_rays_aimed_at_vertices_in_strict_mode():
     r_o, h_o, _ = osc.intersect(f, rays)
     differ = {}
     for strict in (1, 0):
-        c = _ctx_with_env(RT_AMD_STRICT_INTERSECT=strict)
+        c = _ctx_with(strict_intersect=strict)
         c.upload_scene(scn)
         c.set_features(f)
         r_g, h_g = c.intersect(rays)
@@ -736,7 +736,7 @@ def test_cpp_host_mirror():
     """The C++ host API (rt_host.hpp: Scene / BVH / Trackball / renderImage with the
     reference's names) against the reference's pyramid test and the oracle."""
     import subprocess
-    exe = os.path.join(common.ROOT, "ray-tracer_amd", "host", "host_tests")
+    exe = os.path.join(common.ROOT, "tests", "cpp", "host_tests")
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(out.stdout[-600:])
@@ -802,17 +802,64 @@ def test_largest_configurations_features_match_the_oracle(ctx):
     assert maxabs <= 2e-5 and rmse <= 2e-6 and ref.any()
 
 
-def _ctx_with_env(**env):  # (defined below the tests that use it; resolved at call time)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
-        return capi.Context(0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def test_lights_resent_between_two_frames_in_flight():
+    """scene.lights changes between two renderImage calls (the reference's GUI does that,
+    src/main.cpp:340-418).  Through the asynchronous entry point both frames are enqueued on one stream
+    before the first has run: the second set of lights must reach the device behind the first frame."""
+    import copy
+    import torch
+    scn = copy.deepcopy(common.scene("CornellBox"))
+    A = [sio.point_light((0.0, 0.58, 0.0), (1.0, 1.0, 1.0))]
+    B = [sio.point_light((0.3, 0.2, 0.3), (0.2, 0.9, 0.4)), sio.cornell_parallelogram_light()]
+    f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, numPixelSamples=16, numShadowSamples=2)
+    w, h = 320, 240
+    cam = sio.default_camera(w, h)
+    c = _ctx_with()
+    scn.lights = A
+    c.upload_scene(scn)
+    c.set_features(f)
+    want = []
+    for lights in (A, B):
+        c.set_lights(np.stack(lights))
+        want.append(c.render(cam, w, h)[0])
+    assert not np.array_equal(want[0], want[1])
+    stream = torch.cuda.Stream()
+    outs = [torch.zeros(w * h * 3, dtype=torch.float32, device="cuda") for _ in range(4)]
+    for k, lights in enumerate((A, B, A, B)):
+        c.set_lights(np.stack(lights))
+        c.render_device(cam, w, h, outs[k].data_ptr(), outs[k].numel(), 0, 1, stream.cuda_stream)
+    c.sync(stream.cuda_stream)
+    for k in range(4):
+        assert np.array_equal(outs[k].cpu().numpy().reshape(h, w, 3).view(np.uint32), want[k % 2].view(np.uint32)), k
+    c.close()
+
+
+def test_context_options():
+    c = _ctx_with(timing=0)
+    scn = common.scene("Cube")
+    c.upload_scene(scn)
+    c.set_features(common.features(enableShading=1))
+    import torch
+    out = torch.zeros(32 * 32 * 3, dtype=torch.float32, device="cuda")
+    c.render_device(sio.default_camera(32, 32), 32, 32, out.data_ptr(), out.numel())
+    st = c.sync(0)
+    assert st["rays"] == 32 * 32 and st["launches"] == 0 and st["kernel_ms"] == 0.0  # nothing was timed
+    c.set_option("timing", 1)
+    c.render_device(sio.default_camera(32, 32), 32, 32, out.data_ptr(), out.numel())
+    st = c.sync(0)
+    assert st["launches"] == 1 and st["kernel_ms"] > 0.0
+    for name, bad in (("tree", 3), ("workspace_bytes", 1000)):
+        with pytest.raises(capi.RtError) as e:
+            c.set_option(name, bad)
+        assert e.value.code == -1
+    with pytest.raises(capi.RtError):
+        c._check(capi.lib().rt_ctx_set_option(c.handle, 99, 0))
+    c.close()
+
+
+def _ctx_with(**options):  # (defined below the tests that use it; resolved at call time)
+    """A context of its own with rt_ctx_set_option settings (capi.OPTIONS)."""
+    return capi.Context(0, **options)
 
 
 def test_full_size_frame_properties():
@@ -826,9 +873,9 @@ def test_full_size_frame_properties():
     scn, f, w, h, _ = bench.build_workload("dragon")
     cam = sio.default_camera(w, h)
     results = []
-    for env in (dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=1, RT_AMD_PER_PIXEL=0),
-                dict(RT_AMD_TREE=0, RT_AMD_PER_PIXEL=0), dict(RT_AMD_TREE=2, RT_AMD_PER_PIXEL=1)):
-        c = _ctx_with_env(**env)
+    for env in (dict(tree=2, per_pixel=0), dict(tree=1, per_pixel=0),
+                dict(tree=0, per_pixel=0), dict(tree=2, per_pixel=1)):
+        c = _ctx_with(**env)
         c.upload_scene(scn)
         c.set_features(f)
         img, st = c.render(cam, w, h)

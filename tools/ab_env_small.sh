@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the environment only with this set
 # A/B at 1/8 of the frame's pixels under the environment settings given as arguments
 for e in "$@"; do
   for k in 1 3; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the environment only with this set
 # A/B: bench.py (one frame at a time and three in flight) over the library builds given as arguments
 for lib in "$@"; do
   for k in 1 3; do

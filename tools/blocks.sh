@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the environment only with this set
 # A/B: block size of the traversing kernels (library builds under build_ab/), full frame and 1/8 of its pixels
 for lib in ray-tracer_amd/librt_amd.so build_ab/b128.so build_ab/b64.so; do
   for wh in "1920 1080" "680 382"; do set -- $wh

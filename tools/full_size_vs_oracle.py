@@ -28,8 +28,7 @@ ref, st_o = orc.OracleScene(scene).render(features, cam, w, h)
 print(f"oracle: {st_o['rays']} rays in {time.time() - t0:.1f} s", flush=True)
 imgs = {}
 for tree in (2, 1, 0):
-    os.environ["RT_AMD_TREE"] = str(tree)
-    ctx = capi.Context(0)
+    ctx = capi.Context(0, tree=tree)
     ctx.upload_scene(scene)
     ctx.set_features(features)
     img, st = ctx.render(cam, w, h)

@@ -4,8 +4,8 @@ oracle, which tests boxes the reference's non-conservative way: hit flag, t and 
 
     python tools/fuzz_edges.py [scene] [rays-per-kind] [seeds]
 
-With RT_AMD_STRICT_INTERSECT=1 in the environment the device replays every ray in the reference's own
-order of tests and must agree on every ray.
+With FUZZ_STRICT=1 in the environment the context is put in strict mode (RT_OPT_STRICT_INTERSECT): the
+device replays every ray in the reference's own order of tests and must agree on every ray.
 """
 import importlib
 import os
@@ -25,7 +25,7 @@ per = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
 seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 scn = common.scene(name)
 osc = orc.OracleScene(scn)
-ctx = capi.Context(0)
+ctx = capi.Context(0, strict_intersect=int(os.environ.get("FUZZ_STRICT", "0")))
 ctx.upload_scene(scn)
 f = common.features()
 ctx.set_features(f)

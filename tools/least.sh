@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the environment only with this set
 # smallest batch the path kernel's waves take from the queue, at 1/8 and full frame size
 for l in 8 16 32 64; do
   for wh in "680 382" "1920 1080"; do set -- $wh

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the environment only with this set
 # A/B of environment settings on rank 0 of a stand-in world: tools/mock_ab.sh <world> <env settings>...
 n=$1; shift
 for e in "$@"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the environment only with this set
 # bench.py at full size and at 1/8 of the pixels for several values of the queues' positional share
 for s in 0 8 12 14 16; do
   for wh in "1920 1080" "680 382"; do set -- $wh

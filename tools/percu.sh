@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the environment only with this set
 # fewer persistent blocks per compute unit for the path kernel alone, three frames in flight, several frame sizes
 for wh in "680 382" "960 540" "1360 764" "1920 1080"; do set -- $wh
   for b in 0 1 2 3; do

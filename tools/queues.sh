@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the environment only with this set
 # more hardware queues per process, so that more than three frames in flight really overlap
 for q in 4 8 16; do
   for wh in "680 382" "960 540"; do set -- $wh

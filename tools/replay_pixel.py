@@ -31,8 +31,7 @@ rays = np.zeros(len(rows), dtype=sio.RAY)
 rays["origin"] = bits[:, 0:3]; rays["direction"] = bits[:, 3:6]; rays["t"] = bits[:, 6]
 print(len(rows), "intersect calls in the pixel")
 for tree in (2, 0):
-    os.environ["RT_AMD_TREE"] = str(tree)
-    c = capi.Context(0)
+    c = capi.Context(0, tree=tree)
     c.upload_scene(scn)
     c.set_features(f)
     r, hits = c.intersect(rays)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the environment only with this set
 # bench.py at the full frame and at 1/2, 1/4, 1/8 of its pixels: what a shard of the frame costs
 # (a stand-in for the per-GPU share under tile sharding).  Extra arguments: environment settings.
 for wh in "1920 1080" "1360 764" "960 540" "680 382"; do set -- $wh
