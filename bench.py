@@ -67,7 +67,8 @@ capi = importlib.import_module("ray-tracer_amd.capi")
 sharding = importlib.import_module("ray-tracer_amd.sharding")
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
-FP32_PEAK_TFLOPS = 157.3  # MI355X vector FP32, spec
+FP32_PEAK_TFLOPS = 157.3  # MI355X vector FP32, spec (packed fused multiply-adds)
+SHADER_CLOCK_GHZ = 2.4    # MI355X peak engine clock (GRBM_GUI_ACTIVE / 8 XCDs / kernel time reads 2.4 - 2.5 under this load)
 
 
 def build_workload(name: str):
@@ -135,22 +136,28 @@ def cpu_baseline(scene, features, width, height, scale: int, distance: float = 3
             "sample": f"{size}, {dt:.1f} s, {st['rays']} rays", "rays": int(st["rays"])}
 
 
-def measured_traffic(workload, kernel, world, width, height, distance=3.0):
-    """HBM-side bytes per launch of `kernel` from the committed counter passes
-    (profiles/pmc_traffic_<workload>.json, collected by tools/pmc.sh at N=1 and the
-    workload's own resolution); None when no pass covers this run."""
-    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+def stored_counters(workload, kernel, world, width, height, distance=3.0):
+    """Hardware counters of `kernel`, mean per launch, from the committed passes over this workload
+    (profiles/pmc_counters_<workload>.json, written by tools/pmc.sh at N = 1 and the workload's own
+    resolution), and where they come from; (None, why) when no pass covers this run.  rocprofv3 cannot
+    collect counters inside this process, so these are stored numbers and are labelled so; the hash of the
+    kernel sources stored with them says whether they belong to the library that is running."""
+    path = os.path.join(ROOT, "profiles", f"pmc_counters_{workload}.json")
     if world != 1 or distance != 3.0 or not os.path.exists(path):
-        return None, None
+        return None, "no stored counter pass for this configuration"
     _, _, w0, h0, _ = build_workload(workload)
     if (w0, h0) != (width, height):
-        return None, None
+        return None, "no stored counter pass at this resolution"
     with open(path) as fh:
         doc = json.load(fh)
     k = doc["kernels"].get(kernel)
     if k is None:
-        return None, None
-    return k["fetch_bytes"] + k["write_bytes"], doc["source"] + "; " + doc["summary"]
+        return None, "kernel not in the stored counter pass"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summarise
+    same = pmc_summarise.sources_sha1() == doc.get("sources_sha1")
+    return k, (f"stored: profiles/{doc['summary']} ({doc['source']}); "
+               + ("collected on these kernel sources" if same else "the kernel sources have changed since"))
 
 
 def launch_ranks(n: int) -> int:
@@ -248,6 +255,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    num_cu = 256
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): use --nproc-per-node {args.gpus}")
     if args.launch_check:
@@ -262,6 +270,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the rendering path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -365,12 +374,61 @@ def main():
         else:
             kname, k_ms = "renderKernel", frame_ms
             k_rays, k_inner, k_tris = cst["rays"], cst["inner_nodes"], cst["tri_tests"]
+        k_alone = (alone["shadow_ms"] / per_frame if shadow_ms > 0 else alone["kernel_ms"]) / max(1, alone["launches"])
+        t_alone = max(k_alone, 1e-9) * 1e-3  # seconds one launch takes with the chip to itself
+        # What bounds the kernel is the issue of vector-ALU instructions: a 64-lane wave-instruction holds
+        # one of the 4 x 256 SIMDs for four clocks, and the traversal loop is arithmetic from end to end
+        # (byte permutes, fmas, min/max, compares; profiles/round2_b_*: taking two thirds of its loads off
+        # the vector memory path changes nothing, halving the resident waves costs a third).  The count of
+        # issued wave-instructions is a hardware counter (SQ_INSTS_VALU), which rocprofv3 cannot collect
+        # inside this process: it comes from the committed counter pass over this same launch, the time
+        # from this run's HIP events around the launch on a stream it has to itself.
+        ctrs, ctr_src = stored_counters(args.workload, kname, world, width, height, args.camera_distance)
+        valu_peak = 4 * num_cu * SHADER_CLOCK_GHZ / 4.0  # G wave-instructions / s
+        roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": round(valu_peak, 1),
+                "peak_is": f"{4 * num_cu} SIMDs x {SHADER_CLOCK_GHZ} GHz / 4 clocks per 64-lane instruction",
+                "achieved": None, "frac": None, "counters": ctr_src, "traffic": None}
+        if ctrs and ctrs.get("SQ_INSTS_VALU"):
+            valu = ctrs["SQ_INSTS_VALU"]
+            roof["achieved"] = round(valu / t_alone / 1e9, 2)
+            roof["frac"] = round(valu / t_alone / 1e9 / valu_peak, 4)
+            roof["valu_wave_instructions_per_launch"] = valu
+            roof["valu_wave_instructions_per_ray"] = round(valu / max(1.0, k_rays), 2)
+            if ctrs.get("SQ_THREAD_CYCLES_VALU"):
+                roof["lanes_per_valu"] = round(ctrs["SQ_THREAD_CYCLES_VALU"] / valu, 1)
+            if ctrs.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                acc = ctrs["TCP_TOTAL_CACHE_ACCESSES_sum"]
+                roof["l1_lookups"] = {"per_ray": round(acc / max(1.0, k_rays), 1),
+                                      "per_cu_clock": round(acc / t_alone / (num_cu * SHADER_CLOCK_GHZ * 1e9), 3),
+                                      "note": "one per 16-byte load of one lane; a compute unit serves about one a clock (profiles/round2_a_ta_probe.txt)"}
+            if "fetch_bytes" in ctrs and "write_bytes" in ctrs:
+                roof["traffic"] = ctrs["fetch_bytes"] + ctrs["write_bytes"]
+        # The two figures the scope table asks for, on the same launch alone.  Algorithmic traffic: 64 B per
+        # sibling-pair record visited, 36 B of vertex positions per triangle tested, 28 B ray + 16 B result per
+        # ray -- bytes the algorithm asks for, served by L1 / L2 (the scene is a few MB), which is why they
+        # exceed what HBM could deliver; the HBM-side bytes are the counters' `traffic`.
         alg_bytes = 64.0 * k_inner + 36.0 * k_tris + 44.0 * k_rays
         alg_flops = 26.0 * (k_rays + 2.0 * k_inner) + 50.0 * k_tris
-        k_alone = (alone["shadow_ms"] / per_frame if shadow_ms > 0 else alone["kernel_ms"]) / max(1, alone["launches"])
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        tflops = alg_flops / (k_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic(args.workload, kname, world, width, height, args.camera_distance)
+        roof.update({
+            "kernel": kname, "kernel_ms": round(k_alone, 4), "launches_per_frame": per_frame,
+            "kernel_ms_in_timed_region": round(k_ms, 4),
+            "timing_note": "kernel_ms: HIP events around the launch, one frame at a time; in the timed region frames overlap "
+                           "(frames_in_flight), so a launch there shares the compute units and its event time is no denominator",
+            "frame_device_ms_alone": round(alone["kernel_ms"] / max(1, alone["launches"]), 4),
+            "kernel_rays_per_launch": int(k_rays), "kernel_mrays_per_s": round(k_rays / t_alone / 1e6, 1),
+            "inner_nodes_per_ray": round(k_inner / max(1.0, k_rays), 3), "tri_tests_per_ray": round(k_tris / max(1.0, k_rays), 3),
+            "hbm": {"peak_GBs": HBM_PEAK_GBS,
+                    "measured_GBs": round(roof["traffic"] / t_alone / 1e9, 1) if roof["traffic"] else None,
+                    "measured_frac": round(roof["traffic"] / t_alone / 1e9 / HBM_PEAK_GBS, 4) if roof["traffic"] else None,
+                    "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_ray": round(alg_bytes / max(1.0, k_rays), 1),
+                    "algorithmic_GBs": round(alg_bytes / t_alone / 1e9, 1),
+                    "note": "the algorithmic bytes are cache-served; HBM is not this kernel's roof"},
+            "fp32": {"achieved_tflops": round(alg_flops / t_alone / 1e12, 3), "peak_tflops": FP32_PEAK_TFLOPS,
+                     "frac": round(alg_flops / t_alone / 1e12 / FP32_PEAK_TFLOPS, 4),
+                     "note": "peak counts packed fused multiply-adds on all lanes (4 flops per lane and instruction); a scalar-per-lane "
+                             "compare or permute is worth a quarter of that at best"},
+            "frame_device_ms_in_timed_region": {"all_kernels": round(frame_ms, 4), "cameraKernel+pathKernel": round(path_ms, 4),
+                                                "shadowTraceKernel": round(shadow_ms, 4)}})
         out = {
             "metric": "Mrays/s (whole node) on dragon.obj 1080p 16spp; ms/frame" if args.workload == "dragon"
                       else f"Mrays/s ({args.workload})",
@@ -381,24 +439,7 @@ def main():
             "config": {"workload": desc, "rays_per_frame": int(rays_total),
                        "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)", "frames_in_flight": lanes,
                        "scene_note": "dragon.obj is absent from the reference snapshot; procedural stand-in with the same triangle count"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kname, "kernel_ms": round(k_ms, 4), "launches_per_frame": per_frame,
-                         "one_frame_alone": {"kernel_ms": round(k_alone, 4), "frame_device_ms": round(alone["kernel_ms"] / max(1, alone["launches"]), 4),
-                                             "achieved": round(alg_bytes / (k_alone * 1e-3) / 1e9, 2) if k_alone > 0 else None,
-                                             "frac": round(alg_bytes / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_alone > 0 else None,
-                                             "note": "with several frames in flight a launch shares the compute units with the neighbouring "
-                                                     "frames' kernels, so kernel_ms above is longer than the kernel takes on its own"},
-                         "kernel_rays_per_launch": int(k_rays),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_ray": round(alg_bytes / max(1.0, k_rays), 2),
-                         "inner_nodes_per_ray": round(k_inner / max(1.0, k_rays), 3),
-                         "tri_tests_per_ray": round(k_tris / max(1.0, k_rays), 3),
-                         "kernel_mrays_per_s": round(k_rays / (k_ms * 1e-3) / 1e6, 1),
-                         "fp32": {"achieved_tflops": round(tflops, 4), "peak_tflops": FP32_PEAK_TFLOPS,
-                                  "frac": round(tflops / FP32_PEAK_TFLOPS, 5)},
-                         "frame_device_ms": {"all_kernels": round(frame_ms, 4), "cameraKernel+pathKernel": round(path_ms, 4),
-                                             "shadowTraceKernel": round(shadow_ms, 4)}},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu:
             scale = args.cpu_scale

@@ -3,5 +3,5 @@ export RT_AMD_EXPERIMENTS=1 # the library reads its scheduling knobs from the en
 # A/B of environment settings on rank 0 of a stand-in world: tools/mock_ab.sh <world> <env settings>...
 n=$1; shift
 for e in "$@"; do
-  echo "N=$n $e: $(env $e timeout -k 10 200 python tools/mock_world.py $n --steps 60 --warmup 6 --no-cpu 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"ms_per_step\"], d[\"value\"], d[\"roofline\"][\"frame_device_ms\"])")"
+  echo "N=$n $e: $(env $e timeout -k 10 200 python tools/mock_world.py $n --steps 60 --warmup 6 --no-cpu 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"ms_per_step\"], d[\"value\"], d[\"roofline\"][\"frame_device_ms_in_timed_region\"])")"
 done

@@ -11,11 +11,12 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 pass() { # name, counters
   timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d "$out/$1" -o p -- \
-    python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu --workload "$wl" > "$out/$1.log" 2>&1 || { echo "pass $1 failed"; exit 1; }
+    python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu --workload "$wl" ${PMC_BENCH_ARGS:-} > "$out/$1.log" 2>&1 || { echo "pass $1 failed"; exit 1; }
 }
 pass fetch "FETCH_SIZE GRBM_GUI_ACTIVE" &&
 pass write "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" &&
 pass sq "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU" &&
 pass mix "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA TA_BUSY_avr GRBM_GUI_ACTIVE" &&
 pass l1 "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_REQ_sum" &&
-python3 "$root/tools/pmc_summarise.py" "$out" > "$out/summary.txt"
+python3 "$root/tools/pmc_summarise.py" "$out" > "$out/summary.txt" &&
+python3 "$root/tools/pmc_summarise.py" "$out" --counters "$wl" "${PMC_SUMMARY_NAME:-summary.txt}" > "$out/pmc_counters_$wl.json"

@@ -4,6 +4,8 @@
     python3 tools/pmc_summarise.py <dir>          # text summary on stdout
     python3 tools/pmc_summarise.py <dir> --json   # {"kernel": {"counter": mean per launch}}
     python3 tools/pmc_summarise.py <dir> --traffic  # {"kernel": {"fetch_bytes", "write_bytes"}} per launch
+    python3 tools/pmc_summarise.py <dir> --counters <workload> <summary-file>
+                                                  # what bench.py reads: profiles/pmc_counters_<workload>.json
 """
 import csv
 import glob
@@ -31,9 +33,42 @@ def collect(root: str):
     return out
 
 
+def sources_sha1() -> str:
+    """Hash of the kernel sources: tells bench.py whether stored counters belong to the library it runs."""
+    import hashlib
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray-tracer_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(here)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(here, f), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     root = sys.argv[1]
     data = collect(root)
+    if "--counters" in sys.argv:
+        at = sys.argv.index("--counters")
+        workload, summary = sys.argv[at + 1], sys.argv[at + 2]
+        merged = defaultdict(dict)
+        for pas in data.values():
+            for k, cs in pas.items():
+                if k.startswith("__amd") or re.search(r"<true", k):  # (counting variants: first template argument)
+                    continue
+                merged[re.sub(r"<.*", "", k)].update(cs)
+        for k, cs in merged.items():
+            # FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B: doubled
+            # (an upper bound for narrower requests)
+            if "FETCH_SIZE" in cs:
+                cs["fetch_bytes"] = cs["FETCH_SIZE"] * 2048.0
+            if "WRITE_SIZE" in cs:
+                cs["write_bytes"] = cs["WRITE_SIZE"] * 1024.0
+        print(json.dumps({"workload": workload, "summary": summary, "sources_sha1": sources_sha1(),
+                          "source": "rocprofv3 --pmc, one run per pass (tools/pmc.sh), mean per launch of the non-counting kernels; "
+                                    "FETCH_SIZE doubled as gfx950 tallies 128-B requests at 64 B",
+                          "kernels": merged}, indent=1, sort_keys=True))
+        return
     if "--traffic" in sys.argv:
         # HBM-side bytes per launch: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies
         # 128-B requests at 64 B, so it is doubled (an upper bound for narrower requests)
