@@ -94,11 +94,14 @@ def build_workload(name: str):
         return s, f, 512, 512, "CornellBox preset 512x512, 1 spp, point light, shading + reflections + shadows"
     if name in ("monkey", "cube"):  # src/scene.cpp:75-81 / :29-33
         s = sio.load_scene_prebuilt("Monkey" if name == "monkey" else "CubeTextured", data)
-        sio.attach_synthetic_env_map(s)
+        # six faces of the size of the reference's sky textures (src/scene.cpp:112-115: 1024 x 1024, held as
+        # float3: 12.6 MB each, 75 MB together -- the one read-only input of the path that does not fit L2);
+        # procedural, the PNGs themselves are not carried
+        sio.attach_synthetic_env_map(s, size=1024)
         f = sio.default_features(enableAccelStructure=1, enableShading=1, enableShadows=1, enableNormalInterp=1,
                                  enableTextureMapping=1, enableBilinearTextureFiltering=1, enableEnvironmentMap=1)
         return s, f, 1920, 1080, (f"{'Monkey' if name == 'monkey' else 'CubeTextured'} preset 1920x1080, 1 spp, interpolated normals, "
-                                  "bilinear textures, environment map (synthetic faces)")
+                                  "bilinear textures, environment map (six procedural 1024x1024 float3 faces, 75 MB)")
     if name == "dragon4k":
         s = sio.load_scene_prebuilt("Dragon", data)
         s.lights = [sio.cornell_parallelogram_light()]
