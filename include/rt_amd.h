@@ -214,6 +214,17 @@ const char* rt_last_error(const rt_ctx* ctx);
 int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_node* nodes_out,
                  rt_primitive* prims_out, uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves);
 
+/* The same constructor with its work on the GPU of `ctx` (median split only; with sah_binning != 0 this is
+ * rt_bvh_build): the tree's shape follows from n alone under the split at (n + 1) / 2 and is laid out on the
+ * host; boxes and the per-node sorts by centroid (src/bvh.cpp:208-223) run level by level on the device.  Same
+ * node and primitive arrays as rt_bvh_build, bit for bit: a range in which two centroid coordinates are equal
+ * has no unique sorted arrangement (the reference's sort is not stable), so such ranges are sorted once more by
+ * the host's std::sort from the arrangement they had; host_sorted (optional) receives how many primitives
+ * went that way.  Host pointers in and out, like rt_bvh_build. */
+int rt_bvh_build_device(rt_ctx* ctx, const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_node* nodes_out,
+                        rt_primitive* prims_out, uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves,
+                        uint32_t* host_sorted);
+
 /* Hands the library what renderImage reads through `scene` and `bvh`
  * (src/render.h:17-26): bvh.nodes(), bvh.primitives() (src/bvh_interface.h:64-67),
  * scene.meshes[i].material, the textures they name, the six

@@ -18,7 +18,7 @@ EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_bvh_build", "rt_scene_upload", "rt_lights_set",
     "rt_features_set", "rt_render", "rt_render_device", "rt_shard_floats", "rt_deinterleave", "rt_sync",
     "rt_intersect_batch", "rt_eval_batch", "rt_postprocess_device", "rt_pack_bmp_device", "rt_bmp_header", "rt_write_bmp",
-    "rt_render_device_noalloc", "rt_ctx_set_option",
+    "rt_render_device_noalloc", "rt_ctx_set_option", "rt_bvh_build_device",
 ]
 
 (EVAL_BARYCENTRIC, EVAL_INTERP_NORMAL, EVAL_INTERP_TEXCOORD, EVAL_TEX_NEAREST, EVAL_TEX_BILINEAR,
@@ -136,6 +136,18 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             raise RtError(rc, lib().rt_last_error(self.handle).decode())
+
+    def bvh_build_device(self, prims: np.ndarray, sah_binning: bool = False):
+        """BVH::BVH(scene, features) built on this context's GPU: (nodes, primitives, num_levels, num_leaves,
+        primitives the host had to sort because of equal centroid coordinates)."""
+        prims = np.ascontiguousarray(prims, dtype=sio.PRIMITIVE)
+        n = len(prims)
+        nodes = np.zeros(max(2, 2 * n), dtype=sio.NODE)
+        out = np.zeros(n, dtype=sio.PRIMITIVE)
+        nn, nl, nf, hs = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(lib().rt_bvh_build_device(self.handle, _p(prims), C.c_uint32(n), int(sah_binning), _p(nodes), _p(out),
+                                              C.byref(nn), C.byref(nl), C.byref(nf), C.byref(hs)))
+        return nodes[:nn.value].copy(), out, nl.value, nf.value, hs.value
 
     # -- scene ----------------------------------------------------------
     def upload_scene(self, scene, nodes=None, prims=None, sah_binning=False):

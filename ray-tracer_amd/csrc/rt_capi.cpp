@@ -24,6 +24,7 @@
 #include "rt_device.hpp"
 #include "rt_wavefront.hpp"
 #include "rt_post.hpp"
+#include "rt_build.hpp"
 
 namespace rt {
 hipError_t renderOccupancy(int variant, int blockThreads, size_t ldsBytes, int* blocksPerCU);
@@ -781,6 +782,29 @@ try {
     return RT_OK;
 } catch (...) {
     return caught(nullptr, "rt_bvh_build");
+}
+
+int rt_bvh_build_device(rt_ctx* ctx, const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_node* nodes_out,
+    rt_primitive* prims_out, uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves, uint32_t* host_sorted)
+try {
+    if (!ctx)
+        return fail(nullptr, RT_ERR_INVALID, "rt_bvh_build_device: ctx is NULL");
+    if ((n && !prims_in) || !nodes_out || (n && !prims_out) || !n_nodes || !n_levels || !n_leaves)
+        return fail(ctx, RT_ERR_INVALID, "rt_bvh_build_device: NULL argument");
+    if (host_sorted)
+        *host_sorted = 0;
+    if (sah_binning) // the split position of that builder depends on the data at every node: host code for now
+        return rt_bvh_build(prims_in, n, sah_binning, nodes_out, prims_out, n_nodes, n_levels, n_leaves);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceBuildStats st;
+    std::string err;
+    if (!deviceMedianBuild(prims_in, n, nodes_out, prims_out, n_nodes, n_levels, n_leaves, &st, err))
+        return fail(ctx, RT_ERR_DEVICE, "rt_bvh_build_device: %s", err.c_str());
+    if (host_sorted)
+        *host_sorted = st.primitivesSortedOnHost;
+    return RT_OK;
+} catch (...) {
+    return caught(ctx, "rt_bvh_build_device");
 }
 
 // ---------------------------------------------------------------------------

@@ -743,6 +743,57 @@ def test_cpp_host_mirror():
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("name", ["SingleTriangle", "Cube", "CornellBox", "Monkey", "Teapot", "Dragon"])
+def test_device_bvh_build_equals_the_oracles(ctx, name):
+    """BVH::BVH (src/bvh.cpp:52-101) with its work on the GPU: node and primitive arrays bit for bit those of
+    the oracle's recursive builder (and so of rt_bvh_build), on every bundled scene, plus the shape the
+    reference's own tests pin (tests/bvh_tests.cpp:676-754)."""
+    import time
+    prims = common.scene(name).primitives()
+    t0 = time.perf_counter()
+    nodes, out, levels, leaves, host_sorted = ctx.bvh_build_device(prims)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n_h, p_h, l_h, f_h = capi.bvh_build(prims)
+    t_host = time.perf_counter() - t0
+    n_o, p_o, l_o, f_o = orc.bvh_build(prims)
+    print(f"{name}: {len(prims)} primitives, device build {t_dev * 1e3:.1f} ms ({host_sorted} primitives in ranges with equal "
+          f"coordinates sorted on the host), host build {t_host * 1e3:.1f} ms")
+    assert (levels, leaves) == (l_o, f_o) == (l_h, f_h)
+    assert nodes.tobytes() == n_o.tobytes()
+    assert out.tobytes() == p_o.tobytes()
+    shape = {"SingleTriangle": (2, 1, 1, 1), "Cube": (8, 12, 4, 3), "CornellBox": (16, 32, 8, 4), "Monkey": (512, 967, 256, 9),
+             "Teapot": (8192, 15704, 4096, 13), "Dragon": (65536, 87130, 32768, 16)}[name]
+    assert (len(nodes), len(out), leaves, levels) == shape
+
+
+def test_device_bvh_build_edge_cases(ctx):
+    # nothing at all; fewer primitives than a leaf holds; all centroids equal (every range goes to the host's sort)
+    nodes, out, levels, leaves, _ = ctx.bvh_build_device(np.zeros(0, dtype=sio.PRIMITIVE))
+    n_o, p_o, l_o, f_o = orc.bvh_build(np.zeros(0, dtype=sio.PRIMITIVE))
+    assert nodes.tobytes() == n_o.tobytes() and (levels, leaves) == (l_o, f_o)
+    p = np.zeros(37, dtype=sio.PRIMITIVE)
+    p["v1"]["position"] = (1, 0, 0)
+    p["v2"]["position"] = (0, 1, 0)
+    p["meshID"] = np.arange(37)
+    for k in (3, 9, 37):
+        nodes, out, levels, leaves, host_sorted = ctx.bvh_build_device(p[:k])
+        n_o, p_o, l_o, f_o = orc.bvh_build(p[:k])
+        assert nodes.tobytes() == n_o.tobytes() and out.tobytes() == p_o.tobytes() and (levels, leaves) == (l_o, f_o), k
+        assert host_sorted >= (k if k > 4 else 0)
+    # a large soup with many exactly equal coordinates (vertices on a coarse lattice) and negative zeros
+    rng = np.random.default_rng(1)
+    q = np.zeros(20000, dtype=sio.PRIMITIVE)
+    for v in ("v0", "v1", "v2"):
+        q[v]["position"] = (rng.integers(-6, 7, (len(q), 3)) * 0.25).astype(np.float32)
+    q["v0"]["position"][::7] *= np.float32(-0.0)
+    q["meshID"] = np.arange(len(q)) % 5
+    nodes, out, levels, leaves, host_sorted = ctx.bvh_build_device(q)
+    n_o, p_o, l_o, f_o = orc.bvh_build(q)
+    assert nodes.tobytes() == n_o.tobytes() and out.tobytes() == p_o.tobytes() and (levels, leaves) == (l_o, f_o)
+    assert host_sorted > 0
+
+
 def _center_ray_hits(ctx, cam, w, h):
     """Primitive index and t of the ray through every pixel's centre, in Screen order (device)."""
     ys, xs = np.mgrid[0:h, 0:w]
