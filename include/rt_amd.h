@@ -195,13 +195,19 @@ void rt_ctx_destroy(rt_ctx* ctx);
  *                           reference's box routine loses by rounding for rays aimed exactly at vertices.
  *  RT_OPT_WORKSPACE_BYTES   cap on the working memory of the queue-based renderer (default 64 GiB, never more
  *                           than the device has free); a frame that needs more is rendered in pixel batches.
- *  RT_OPT_TIMING            0 = record no events around the render launches (rt_stats times read 0). */
+ *  RT_OPT_TIMING            0 = record no events around the render launches (rt_stats times read 0).
+ *  RT_OPT_TREE_BUILD        who builds the library's own hierarchy at rt_scene_upload: 0 (default) the host, sweeping
+ *                           every split position of every axis with the surface-area heuristic; 1 the device, with
+ *                           32 bins per axis and all nodes of a level at once -- an upload several times faster
+ *                           (scenes edited between frames) for a tree a few per cent more expensive to traverse.
+ *                           Results do not depend on it. */
 enum rt_option {
     RT_OPT_TREE = 1,
     RT_OPT_PER_PIXEL = 2,
     RT_OPT_STRICT_INTERSECT = 3,
     RT_OPT_WORKSPACE_BYTES = 4,
-    RT_OPT_TIMING = 5
+    RT_OPT_TIMING = 5,
+    RT_OPT_TREE_BUILD = 6
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, int64_t value);
 const char* rt_last_error(const rt_ctx* ctx);

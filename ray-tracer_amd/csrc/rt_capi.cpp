@@ -25,6 +25,7 @@
 #include "rt_wavefront.hpp"
 #include "rt_post.hpp"
 #include "rt_build.hpp"
+#include "rt_tree.hpp"
 
 namespace rt {
 hipError_t renderOccupancy(int variant, int blockThreads, size_t ldsBytes, int* blocksPerCU);
@@ -70,44 +71,6 @@ static hipError_t scratchOnDevice(int device, void** out)
     *out = g_scratchPtr[device];
     return hipSuccess;
 }
-
-struct TreeLeaf {
-    float lo[3], hi[3], c[3];
-    uint32_t ref, count;
-};
-
-// Quantisation grid: 65535 cells per axis across the root box.  A plane q stands
-// for the real number gridMin + q * gridCell (both floats); lower planes round
-// down, upper planes round up, checked in double so the quantised box contains
-// the float box whatever the rounding of the division did.
-struct QuantGrid {
-    float gridMin[3], gridCell[3];
-    uint32_t quantLo(float v, int a) const
-    {
-        if (!(gridCell[a] > 0.0f))
-            return 0u;
-        double q = std::floor((static_cast<double>(v) - gridMin[a]) / gridCell[a]);
-        q = std::min(65535.0, std::max(0.0, q));
-        while (q > 0.0 && static_cast<double>(gridMin[a]) + q * gridCell[a] > static_cast<double>(v))
-            q -= 1.0;
-        return static_cast<uint32_t>(q);
-    }
-    uint32_t quantHi(float v, int a) const
-    {
-        if (!(gridCell[a] > 0.0f))
-            return 65535u; // flat or empty axis: A = 0, every plane sits at gridMin
-        double q = std::ceil((static_cast<double>(v) - gridMin[a]) / gridCell[a]);
-        q = std::min(65535.0, std::max(0.0, q));
-        while (q < 65535.0 && static_cast<double>(gridMin[a]) + q * gridCell[a] < static_cast<double>(v))
-            q += 1.0;
-        return static_cast<uint32_t>(q);
-    }
-    void packBox(const float* lo, const float* hi, uint32_t* w) const
-    {
-        for (int a = 0; a < 3; a++)
-            w[a] = quantLo(lo[a], a) | (quantHi(hi[a], a) << 16);
-    }
-};
 
 struct rt_ctx {
     int device = 0;
@@ -170,6 +133,7 @@ struct rt_ctx {
     // 0 = traverse the caller's inner nodes as they are; 1 = own SAH hierarchy over the caller's leaves;
     // 2 = own SAH hierarchy over the caller's primitives, each a leaf of its own under its own box
     int treeMode = 2;
+    bool treeBuildOnDevice = false; // RT_OPT_TREE_BUILD: the library's own hierarchy by the device's binned builder
     size_t workspaceCap = 64ull << 30; // bytes the wavefront path may hold
     // working memory of the queue-based path (one allocation, grow-only)
     void* wsBase = nullptr;
@@ -385,6 +349,9 @@ try {
         return RT_OK;
     case RT_OPT_TIMING:
         ctx->timing = value != 0;
+        return RT_OK;
+    case RT_OPT_TREE_BUILD:
+        ctx->treeBuildOnDevice = value != 0;
         return RT_OK;
     default:
         return fail(ctx, RT_ERR_INVALID, "rt_ctx_set_option: unknown option %d", option);
@@ -930,7 +897,15 @@ try {
             }
             leaves.push_back(l);
         }
-        ownTree = buildOwnTree(leaves, grid, pairs, rootRef, maxLevel);
+        if (ctx->treeBuildOnDevice) {
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            std::string err;
+            if (!deviceOwnTree(leaves, grid, pairs, rootRef, maxLevel, err))
+                return fail(ctx, RT_ERR_DEVICE, "rt_scene_upload: %s", err.c_str());
+            ownTree = true;
+        } else {
+            ownTree = buildOwnTree(leaves, grid, pairs, rootRef, maxLevel);
+        }
     }
     if (!ownTree) {
         if (callerLevels > (uint32_t)kMaxStack)

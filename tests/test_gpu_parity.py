@@ -289,7 +289,7 @@ def test_primitives_met_at_the_same_distance():
         ref, st_o = osc.render(f, cam, w, h)
         r_o, h_o, _ = osc.intersect(f, rays)
         for env in (dict(tree=2, per_pixel=0), dict(tree=1, per_pixel=0), dict(tree=0, per_pixel=0),
-                    dict(tree=2, per_pixel=1)):
+                    dict(tree=2, per_pixel=1), dict(tree=2, tree_build=1), dict(tree=1, tree_build=1)):
             c = _ctx_with(**env)
             c.upload_scene(scn)
             c.set_features(f)
@@ -468,7 +468,7 @@ def test_triangle_soup_with_degenerate_and_repeated_triangles():
     ref, st_o = osc.render(f_img, cam, w, h)
     assert 0.2 < h_o["hit"].mean() < 1.0 and ref.any()
     for env in (dict(tree=2, per_pixel=0), dict(tree=1, per_pixel=0), dict(tree=0, per_pixel=0),
-                dict(tree=2, per_pixel=1)):
+                dict(tree=2, per_pixel=1), dict(tree=2, tree_build=1), dict(tree=1, tree_build=1)):
         c = _ctx_with(**env)
         c.upload_scene(scn)
         c.set_features(f_hit)
@@ -917,15 +917,15 @@ def test_full_size_frame_properties():
     """BASELINE config 4 at its full size (dragon stand-in, 1920x1080, 16 spp, area light,
     mirror depth 4), too large for the CPU oracle inside a test: the independent device paths
     must agree bit for bit -- wavefront kernels over the library's own hierarchy of single
-    primitives, over its hierarchy of the caller's leaves, over the caller's inner nodes, and
-    the per-pixel kernel that walks every pixel in the reference's depth-first order -- and
-    count the same rays."""
+    primitives (built by the host's sweep and by the device's binned builder), over its hierarchy
+    of the caller's leaves, over the caller's inner nodes, and the per-pixel kernel that walks
+    every pixel in the reference's depth-first order -- and count the same rays."""
     import bench
     scn, f, w, h, _ = bench.build_workload("dragon")
     cam = sio.default_camera(w, h)
     results = []
     for env in (dict(tree=2, per_pixel=0), dict(tree=1, per_pixel=0),
-                dict(tree=0, per_pixel=0), dict(tree=2, per_pixel=1)):
+                dict(tree=0, per_pixel=0), dict(tree=2, per_pixel=1), dict(tree=2, tree_build=1)):
         c = _ctx_with(**env)
         c.upload_scene(scn)
         c.set_features(f)

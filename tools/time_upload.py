@@ -1,10 +1,46 @@
-import sys, time, importlib
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
-import bench
+"""rt_bvh_build / rt_bvh_build_device and rt_scene_upload with the library's own hierarchy built by the host
+(full sweep) or by the device (binned), on a bench workload: times, and what the tree costs the headline frame."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch  # noqa: E402,F401
+import bench  # noqa: E402
+
 capi = importlib.import_module("ray-tracer_amd.capi")
-scene, f, w, h, _ = bench.build_workload("dragon")
+sio = importlib.import_module("ray-tracer_amd.scene_io")
+scene, f, w, h, desc = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "dragon")
+print(desc)
 prims = scene.primitives()
-t=time.time(); nodes, p, nl, nf = capi.bvh_build(prims); print("rt_bvh_build %.3f s"%(time.time()-t))
+t = time.perf_counter(); nodes, p, nl, nf = capi.bvh_build(prims); print(f"rt_bvh_build (host)          {1e3 * (time.perf_counter() - t):7.1f} ms")
 ctx = capi.Context(0)
-for i in range(3):
-    t=time.time(); ctx.upload_scene(scene, nodes, p); print("rt_scene_upload (with lights) %.3f s"%(time.time()-t))
+for _ in range(2):
+    t = time.perf_counter(); n2, p2, _, _, hs = ctx.bvh_build_device(prims)
+    print(f"rt_bvh_build_device          {1e3 * (time.perf_counter() - t):7.1f} ms  ({hs} primitives in ranges sorted by the host; arrays equal: "
+          f"{n2.tobytes() == nodes.tobytes() and p2.tobytes() == p.tobytes()})")
+ctx.close()
+cam = sio.default_camera(w, h)
+frames = {}
+for build in (0, 1):
+    c = capi.Context(0, tree_build=build)
+    for _ in range(3):
+        t = time.perf_counter(); c.upload_scene(scene, nodes, p); dt = time.perf_counter() - t
+    c.set_features(f)
+    out = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    c.render_device(cam, w, h, out.data_ptr(), out.numel())
+    c.sync(0)
+    ms = []
+    for _ in range(5):
+        c.render_device(cam, w, h, out.data_ptr(), out.numel())
+        ms.append(c.sync(0)["kernel_ms"])
+    st = c.render_device(cam, w, h, out.data_ptr(), out.numel(), collect_stats=True)
+    frames[build] = out.cpu().numpy()
+    print(f"own hierarchy by the {'device (binned)' if build else 'host (full sweep)'}: rt_scene_upload {1e3 * dt:6.1f} ms; frame {np.median(ms):.3f} ms, "
+          f"{st['rays']} rays, {st['shadow_inner_nodes'] / max(1, st['shadow_rays']):.2f} pair records and {st['shadow_tri_tests'] / max(1, st['shadow_rays']):.2f} triangles per shadow ray")
+    c.close()
+print("frames equal bit for bit:", np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)))
