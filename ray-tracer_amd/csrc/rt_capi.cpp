@@ -1271,6 +1271,53 @@ static int traceKnobs(int minActive, int a, int b)
     return c(minActive) | (c(a) << 8) | (c(b) << 16);
 }
 
+// For every 8x8 tile of this shard, how many of its pixels can have a camera ray that enters the scene's box
+// (the root box test of BVHInterface::intersect, src/bvh.cpp:253-259): the pixels inside the bounding
+// rectangle of the box's eight corners as the camera sees them (Trackball::generateRay,
+// framework/src/trackball.cpp:101-110), a pixel wider on every side.  Only such pixels can make hits, so
+// only they need room in the pools of hits and light samples.  Every real pixel counts when the bound
+// does not apply: a corner beside or behind the camera, rays that start on a lens instead of the camera's
+// position (depth of field), spheres in the scene or the acceleration structure off (every ray is traced).
+static std::vector<uint16_t> candidatePixelsPerTile(const rt_ctx* ctx, const rt_camera& camera, const DevFrame& fr, int width, int height)
+{
+    const uint32_t nTiles = fr.nWork / 64u;
+    std::vector<uint16_t> out(nTiles);
+    const rt_features& F = ctx->features;
+    const DevScene& sc = ctx->scene;
+    bool bounded = F.enableAccelStructure && !F.enableDepthOfField && sc.nSpheres == 0 && sc.nPrims != 0;
+    int x0 = 0, x1 = width - 1, y0 = 0, y1 = height - 1; // inclusive pixel rectangle
+    if (bounded) {
+        const DevCamera cam = makeCamera(camera);
+        const f3 qInv = { -cam.q.x, -cam.q.y, -cam.q.z };
+        double lox = 1e300, hix = -1e300, loy = 1e300, hiy = -1e300;
+        for (int k = 0; k < 8 && bounded; k++) {
+            const f3 c = { (k & 1) ? sc.rootHi[0] : sc.rootLo[0], (k & 2) ? sc.rootHi[1] : sc.rootLo[1], (k & 4) ? sc.rootHi[2] : sc.rootLo[2] };
+            const f3 v = quatRotate(cam.qw, qInv, c - cam.pos); // the corner in the camera's frame: rays leave along +z
+            if (!(v.z > 1.0e-3f) || !std::isfinite(v.x) || !std::isfinite(v.y)) {
+                bounded = false;
+                break;
+            }
+            // direction (-x halfW, y halfH, 1) of normalised device coordinates (x, y); pixel = (ndc + 1) / 2 * size
+            const double nx = -double(v.x) / (double(v.z) * cam.halfW), ny = double(v.y) / (double(v.z) * cam.halfH);
+            const double px = (nx + 1.0) * 0.5 * width, py = (ny + 1.0) * 0.5 * height;
+            lox = std::min(lox, px), hix = std::max(hix, px), loy = std::min(loy, py), hiy = std::max(hiy, py);
+        }
+        if (bounded) {
+            // a pixel holds the samples [p, p + 1); one more pixel on every side for the roundings of either computation
+            x0 = static_cast<int>(std::max(0.0, std::floor(lox) - 1.0)), x1 = static_cast<int>(std::min(double(width - 1), std::floor(hix) + 1.0));
+            y0 = static_cast<int>(std::max(0.0, std::floor(loy) - 1.0)), y1 = static_cast<int>(std::min(double(height - 1), std::floor(hiy) + 1.0));
+        }
+    }
+    for (uint32_t t = 0; t < nTiles; t++) {
+        const uint64_t tile = static_cast<uint64_t>(t) * fr.nShard + fr.shard;
+        const int tx = static_cast<int>(tile % fr.tilesX) * kTile, ty = static_cast<int>(tile / fr.tilesX) * kTile;
+        const int ax = std::max(tx, x0), bx = std::min(std::min(tx + kTile, width) - 1, x1);
+        const int ay = std::max(ty, y0), by = std::min(std::min(ty + kTile, height) - 1, y1);
+        out[t] = (bx >= ax && by >= ay) ? static_cast<uint16_t>((bx - ax + 1) * (by - ay + 1)) : 0;
+    }
+    return out;
+}
+
 // `arena`: null = working buffers are the context's own (allocated and grown as needed); else they
 // are carved from it and the call allocates nothing, times nothing (events are allocations too) and
 // splits the frame into as many pixel batches as the arena's size asks for.
@@ -1452,8 +1499,6 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         else if (mirrors || passes)
             nodesPerPath = static_cast<uint64_t>(F.maxRayDepth) + 1;
         const uint64_t nodesPerPixel = static_cast<uint64_t>(wp.R) * nodesPerPath;
-        const uint64_t bytesPerPixel = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + 32 + (F.enableEnvironmentMap ? 12 : 0))
-            + nodesPerPixel * perNodeBytes;
         // what does not shrink with the batch: the unused ends of the node blocks, the buffers' alignment
         const uint64_t fixedBytes = nodeSlack * perNodeBytes + 16 * 256;
         // item index (node * slots + slot) in 32 bits, with room for the queue head to run past the end
@@ -1461,23 +1506,56 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         const uint64_t nodeCap = (0xffffffffull - (1ull << 26)) / std::max(1u, slots);
         if (nodeCap <= nodeSlack)
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u light samples per hit exceed the supported count", slots);
-        // pixel slots (whole tiles) of one batch under a cap on the working memory
-        auto slotsUnder = [&](uint64_t cap, uint64_t fixed) {
-            uint64_t n = (cap > fixed ? cap - fixed : 0) / std::max<uint64_t>(1, bytesPerPixel);
-            n = std::min<uint64_t>(n, 0x7fffffffull / wp.R); // path index in 31 bits
-            n = std::min<uint64_t>(n, (nodeCap - nodeSlack) / nodesPerPixel);
-            return std::min<uint64_t>(n, fr.nWork) & ~63ull;
+
+        // Which pixels can have a camera ray that enters the scene's box at all: only those make hits, and the
+        // pools of hits and light samples -- nine tenths of the working memory -- are sized for them alone.
+        const std::vector<uint16_t> tileCand = candidatePixelsPerTile(ctx, *camera, fr, width, height);
+        const uint32_t nTiles = fr.nWork / 64u;
+        // per pixel slot: head, count, prefix (and environment colour) of each of its camera rays; per candidate
+        // pixel: its queued camera rays and the worst case of its hits with their light samples
+        const uint64_t perSlot = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + (F.enableEnvironmentMap ? 12 : 0));
+        const uint64_t perCand = static_cast<uint64_t>(wp.R) * 32 + nodesPerPixel * perNodeBytes;
+        struct Batch {
+            uint32_t firstTile, tiles;
+            uint64_t cand;
+        };
+        std::vector<Batch> batches;
+        uint64_t maxTiles = 0, maxCand = 0;
+        // consecutive tiles, as many as the cap lets in; false when one tile alone exceeds it
+        auto plan = [&](uint64_t cap, uint64_t fixed) {
+            batches.clear();
+            maxTiles = maxCand = 0;
+            const uint64_t room = cap > fixed ? cap - fixed : 0;
+            Batch cur { 0u, 0u, 0ull };
+            for (uint32_t t = 0; t < nTiles; t++) {
+                const uint64_t tiles = cur.tiles + 1ull, cand = cur.cand + tileCand[t];
+                const bool fits = tiles * 64 * perSlot + cand * perCand <= room && tiles * 64 * wp.R <= 0x7fffffffull // path index in 31 bits
+                    && cand * nodesPerPixel + nodeSlack <= nodeCap;
+                if (!fits) {
+                    if (cur.tiles == 0)
+                        return false;
+                    batches.push_back(cur);
+                    cur = Batch { t, 0u, 0ull };
+                    t--; // this tile opens the next batch
+                    continue;
+                }
+                cur.tiles = static_cast<uint32_t>(tiles), cur.cand = cand;
+                maxTiles = std::max<uint64_t>(maxTiles, tiles), maxCand = std::max<uint64_t>(maxCand, cand);
+            }
+            if (cur.tiles)
+                batches.push_back(cur);
+            return true;
         };
         size_t want[10];
         uint64_t maxNodes = 0;
-        auto sizesFor = [&](uint64_t batch) { // the ten buffers of a batch of that many pixel slots; returns their sum
-            const uint64_t paths = batch * wp.R;
-            maxNodes = batch * nodesPerPixel + nodeSlack;
+        auto sizes = [&]() { // the ten buffers for the largest batch of the plan; returns their sum
+            const uint64_t paths = maxTiles * 64 * wp.R, queued = std::max<uint64_t>(1, maxCand * wp.R);
+            maxNodes = maxCand * nodesPerPixel + nodeSlack;
             const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, slots);
             const size_t w[10] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
                 F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
                 static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * (transp ? 48 : 32), transp ? items : 16,
-                static_cast<size_t>(paths) * 32 };
+                static_cast<size_t>(queued) * 32 };
             size_t total = 0;
             for (int i = 0; i < 10; i++)
                 want[i] = w[i], total += (w[i] + 255) & ~size_t(255);
@@ -1485,11 +1563,10 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         };
         // (RT_OPT_WORKSPACE_BYTES caps what grows with the batch; memory that is really there -- an arena, or
         // what the device has free, below -- has to hold the fixed part as well)
-        uint64_t batchSlots = slotsUnder(workspaceCap, arena ? fixedBytes : 0);
-        if (batchSlots == 0)
+        if (!plan(workspaceCap, arena ? fixedBytes : 0))
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: one 8x8 tile of this frame needs %llu bytes of working memory, more than the %zu-byte %s",
-                static_cast<unsigned long long>(64 * bytesPerPixel + fixedBytes), workspaceCap, arena ? "scratch left" : "workspace");
-        size_t total = sizesFor(batchSlots);
+                static_cast<unsigned long long>(64 * (perSlot + perCand) + fixedBytes), workspaceCap, arena ? "scratch left" : "workspace");
+        size_t total = sizes();
         Arena own { nullptr, 0, 0 };
         if (!arena) {
             // The context's own working memory: one allocation, grown when a frame asks for more.  All sizes are
@@ -1500,11 +1577,10 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                 HIP_TRY(ctx, hipMemGetInfo(&freeB, &totalB));
                 const size_t allowed = ctx->wsBytes + freeB - freeB / 8;
                 if (total > allowed) {
-                    batchSlots = slotsUnder(allowed, fixedBytes);
-                    if (batchSlots == 0)
+                    if (!plan(allowed, fixedBytes))
                         return fail(ctx, RT_ERR_DEVICE, "render: %zu bytes of device memory are free, one 8x8 tile of this frame needs %llu",
-                            freeB, static_cast<unsigned long long>(64 * bytesPerPixel + fixedBytes));
-                    total = sizesFor(batchSlots);
+                            freeB, static_cast<unsigned long long>(64 * (perSlot + perCand) + fixedBytes));
+                    total = sizes();
                 }
                 HIP_TRY(ctx, hipStreamSynchronize(stream)); // (frames still in flight on this stream use the old buffer)
                 if (ctx->wsBase)
@@ -1513,6 +1589,13 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                 ctx->wsBytes = 0;
                 HIP_TRY(ctx, hipMalloc(&ctx->wsBase, total));
                 ctx->wsBytes = total;
+                if (getenv("RT_AMD_DEBUG_COUNTERS")) {
+                    uint64_t cand = 0;
+                    for (uint16_t c : tileCand)
+                        cand += c;
+                    fprintf(stderr, "[rt_amd] working memory %.2f GB for %zu batch(es): %llu of %llu pixels can see the scene's box\n", total / 1e9,
+                        batches.size(), static_cast<unsigned long long>(cand), static_cast<unsigned long long>(fr.nWork));
+                }
             }
             own = Arena { static_cast<char*>(ctx->wsBase), ctx->wsBytes, 0 };
             arena = &own;
@@ -1537,15 +1620,16 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         wb.camRays = static_cast<float4*>(ws[9]);
         wb.maxNodes = static_cast<uint32_t>(maxNodes);
 
-        for (uint64_t begin = 0; begin < fr.nWork; begin += batchSlots) {
+        for (const Batch& bt : batches) {
+            const uint64_t begin = static_cast<uint64_t>(bt.firstTile) * 64;
             wp.slotBegin = static_cast<uint32_t>(begin);
-            wp.nSlots = static_cast<uint32_t>(std::min<uint64_t>(batchSlots, fr.nWork - begin));
+            wp.nSlots = bt.tiles * 64u;
             if (begin != 0) // queue heads and the node allocator start over; the ray counters keep adding up
                 HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(dCounters) + offsetof(DevCounters, next), 0,
                     offsetof(DevCounters, loopIters) - offsetof(DevCounters, next), stream));
             // real pixels of the batch's tiles (edge tiles are padded to 8x8 slots)
             uint64_t validPixels = 0;
-            for (uint64_t t = begin / 64; t < (begin + wp.nSlots) / 64; t++) {
+            for (uint64_t t = bt.firstTile; t < static_cast<uint64_t>(bt.firstTile) + bt.tiles; t++) {
                 const uint64_t tile = t * static_cast<uint64_t>(nShard) + shard;
                 const int tx = static_cast<int>(tile % fr.tilesX), ty = static_cast<int>(tile / fr.tilesX);
                 validPixels += static_cast<uint64_t>(std::min(kTile, width - tx * kTile)) * std::min(kTile, height - ty * kTile);
