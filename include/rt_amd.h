@@ -31,7 +31,7 @@ extern "C" {
 enum rt_status {
     RT_OK = 0,
     RT_ERR_INVALID = -1,     /* bad argument / malformed BVH */
-    RT_ERR_UNSUPPORTED = -2, /* feature outside this path (motion blur, bloom sizes the reference cannot run) */
+    RT_ERR_UNSUPPORTED = -2, /* outside this path (bloom sizes the reference cannot run, sample counts beyond a counter's width) */
     RT_ERR_DEVICE = -3,      /* HIP runtime failure */
     RT_ERR_STATE = -4,       /* call order (render before scene upload, ...) */
     RT_ERR_NOMEM = -5,       /* host memory ran out inside the library */
@@ -114,9 +114,9 @@ typedef struct {
     int32_t enableEnvironmentMap;
     int32_t enableGlossyReflection;
     int32_t enableMipmapTextureFiltering;
-    int32_t enableMotionBlur;
-    int32_t motionBlurSamples;
-    float movement;
+    int32_t enableMotionBlur;  /* renderImageWithMotionBlur, src/extra.cpp:121-211; depth of field, if also on, takes the frame (src/render.cpp:22-25) */
+    int32_t motionBlurSamples; /* time samples per pixel, at most 65535 */
+    float movement;            /* splineMat's scale, src/extra.cpp:546-567 */
     uint32_t numGlossySamples;
     float glossyExponent;
     uint32_t bloomFilterSize;

@@ -110,6 +110,19 @@ class OracleScene:
             raise RuntimeError("oracle: unsupported feature combination")
         return out, st.as_dict()
 
+    def render_motion_blur(self, scene_order_prims, features, camera, width, height, threads=0):
+        """renderImageWithMotionBlur; scene_order_prims = scene.primitives(), the order the meshes hold them in."""
+        out = np.zeros((height, width, 3), dtype=np.float32)
+        st = Stats()
+        f = np.ascontiguousarray(features, dtype=sio.FEATURES)
+        cam = np.ascontiguousarray(camera, dtype=sio.CAMERA)
+        prims = np.ascontiguousarray(scene_order_prims, dtype=sio.PRIMITIVE)
+        rc = lib().orc_render_motion_blur(self.handle, _p(prims), C.c_uint32(len(prims)), _p(f), _p(cam), width, height,
+                                          _p(out), C.byref(st), threads)
+        if rc != 0:
+            raise RuntimeError("oracle: motion blur is off, or depth of field takes the frame")
+        return out, st.as_dict()
+
     def primary_hits(self, features, camera, width, height):
         prim = np.zeros((height, width), dtype=np.int32)
         t = np.zeros((height, width), dtype=np.float32)

@@ -1219,8 +1219,8 @@ void orc_bmp_bytes(const float* rgb, int width, int height, uint8_t* out)
 int orc_render(const orc_scene* scene, const orc_features* features, const orc_camera* camera, int width, int height,
     float* out_rgb, orc_stats* stats, int policy, int threads)
 {
-    if (features->enableMotionBlur)
-        return -1;
+    if (features->enableMotionBlur && !features->enableDepthOfField)
+        return -1; // orc_render_motion_blur, which needs the primitives in the scene's order on top
     if (features->enableBloomEffect && (features->bloomFilterSize < 3 || features->bloomFilterSize > 20))
         return -1;
     const Camera cam(*camera);
@@ -1265,6 +1265,128 @@ int orc_render(const orc_scene* scene, const orc_features* features, const orc_c
     if (dumpFile)
         std::fclose(dumpFile);
     return orc_bloom(features, out_rgb, width, height); // src/render.cpp:48-50
+}
+
+namespace {
+
+// splineMat (src/extra.cpp:546-567) applied to a position the way renderImageWithMotionBlur applies it
+// (src/extra.cpp:152-154, :171-173): the Bezier point of the five control points offset * movement +
+// position, glm::translate(mat4(1), point) (ext/matrix_transform.inl:13), the mat4 * vec4 product
+// (detail/type_mat4x4.inl:561-572) and the division by w.
+V3 movedPosition(float t, V3 currentCenter, float movement)
+{
+    const V3 p0 = (V3 { 0.0f, 0.0f, 0.0f } * movement) + currentCenter;
+    const V3 p1 = (V3 { 0.0f, 1.0f, 1.0f } * movement) + currentCenter;
+    const V3 p2 = (V3 { 1.0f, 1.0f, -1.0f } * movement) + currentCenter;
+    const V3 p3 = (V3 { 1.0f, 0.0f, 0.0f } * movement) + currentCenter;
+    const V3 p4 = (V3 { 1.5f, 1.0f, 2.0f } * movement) + currentCenter;
+    const float oneMinusT = 1.0f - t;
+    const float oneMinusTSquared = oneMinusT * oneMinusT;
+    const float tSquared = t * t;
+    const float tCubed = tSquared * t;
+    const V3 posBezier = (oneMinusTSquared * oneMinusTSquared * p0) + (4.0f * oneMinusTSquared * oneMinusT * t * p1)
+        + (6.0f * oneMinusTSquared * tSquared * p2) + (4.0f * oneMinusT * tCubed * p3) + (tSquared * tSquared * p4);
+    // columns of the identity, then Result[3] = m[0] * v[0] + m[1] * v[1] + m[2] * v[2] + m[3]
+    float m[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
+    float col3[4];
+    for (int r = 0; r < 4; r++)
+        col3[r] = ((m[0][r] * posBezier.x + m[1][r] * posBezier.y) + m[2][r] * posBezier.z) + m[3][r];
+    for (int r = 0; r < 4; r++)
+        m[3][r] = col3[r];
+    const float v[4] = { currentCenter.x, currentCenter.y, currentCenter.z, 1.0f };
+    float out[4];
+    for (int r = 0; r < 4; r++) {
+        const float add0 = m[0][r] * v[0] + m[1][r] * v[1];
+        const float add1 = m[2][r] * v[2] + m[3][r] * v[3];
+        out[r] = add0 + add1;
+    }
+    return V3 { out[0] / out[3], out[1] / out[3], out[2] / out[3] };
+}
+
+} // namespace
+
+// renderImageWithMotionBlur (src/extra.cpp:121-211) followed by the bloom pass of renderImage
+// (src/render.cpp:48-50).  Per pixel and per time sample the reference copies the scene with every
+// vertex and sphere centre moved, builds a BVH over the copy (BVH::BVH takes the meshes' triangles in
+// the scene's order, which is why this function wants the primitives in THAT order, not the order a
+// built tree leaves them in) and renders the pixel's rays in it with a copy of the pixel's sampler.
+// One deviation, which the reference's undefined behaviour forces: the sum over the time samples
+// starts at zero here, where the reference adds into an uninitialised vector (src/extra.cpp:144, :205).
+int orc_render_motion_blur(const orc_scene* scene, const orc_primitive* scene_order_prims, uint32_t n_prims,
+    const orc_features* features, const orc_camera* camera, int width, int height, float* out_rgb, orc_stats* stats,
+    int threads)
+{
+    if (!features->enableMotionBlur || features->enableDepthOfField)
+        return -1;
+    if (features->enableBloomEffect && (features->bloomFilterSize < 3 || features->bloomFilterSize > 20))
+        return -1;
+    const Camera cam(*camera);
+    const int samples = features->motionBlurSamples;
+    const float movement = features->movement;
+    orc_stats total {};
+#ifdef _OPENMP
+    const int nthreads = threads > 0 ? threads : omp_get_max_threads();
+#else
+    const int nthreads = 1;
+#endif
+#pragma omp parallel num_threads(nthreads)
+    {
+        orc_stats local {};
+        // the copy of the scene: everything but nodes, primitives and spheres stays as it is
+        orc_scene newScene;
+        newScene.materials = scene->materials;
+        newScene.images = scene->images; // texel storage stays with the original
+        for (int i = 0; i < 6; i++)
+            newScene.envFaces[i] = scene->envFaces[i];
+        newScene.lights = scene->lights;
+        std::vector<orc_primitive> movedPrims(n_prims);
+#pragma omp for schedule(guided)
+        for (int y = 0; y < height; y++) {
+            for (int x = 0; x != width; x++) {
+                State state { *scene, *features, Sampler { static_cast<uint32_t>(height * x + y) } };
+                V3 L = v3(0.0f);
+                for (int i = 0; i < samples; i++) {
+                    const float time = state.sampler.next_1d();
+                    newScene.spheres = scene->spheres;
+                    for (orc_sphere& sp : newScene.spheres) {
+                        const V3 c = movedPosition(time, v3(sp.center), movement);
+                        sp.center[0] = c.x, sp.center[1] = c.y, sp.center[2] = c.z;
+                    }
+                    for (uint32_t k = 0; k < n_prims; k++) {
+                        orc_primitive q = scene_order_prims[k];
+                        for (orc_vertex* vtx : { &q.v0, &q.v1, &q.v2 }) {
+                            const V3 c = movedPosition(time, v3(vtx->position), movement);
+                            vtx->position[0] = c.x, vtx->position[1] = c.y, vtx->position[2] = c.z;
+                        }
+                        movedPrims[k] = q;
+                    }
+                    Builder b; // BVH newBvh = BVH(newScene, features), src/extra.cpp:196
+                    b.sahBinning = features->enableBvhSahBinning != 0;
+                    b.out.reserve(n_prims);
+                    b.nodes.reserve(n_prims + 1);
+                    b.nodes.emplace_back();
+                    b.nodes.emplace_back();
+                    std::memset(&b.nodes[1], 0, sizeof(orc_node));
+                    b.nodes[1].upper[0] = b.nodes[1].upper[1] = b.nodes[1].upper[2] = 1.0f;
+                    b.buildRecursive(movedPrims.data(), n_prims, 0);
+                    newScene.nodes.swap(b.nodes);
+                    newScene.prims.swap(b.out);
+                    State newState { newScene, *features, state.sampler };
+                    const std::vector<Ray> rays = generatePixelRays(newState, cam, x, y, width, height);
+                    L += renderRays(newState, rays);
+                    addStats(local, newState.stats);
+                }
+                L = L / static_cast<float>(samples);
+                float* px = out_rgb + 3 * (size_t(height - 1 - y) * width + x);
+                px[0] = L.x, px[1] = L.y, px[2] = L.z;
+            }
+        }
+#pragma omp critical
+        addStats(total, local);
+    }
+    if (stats)
+        *stats = total;
+    return orc_bloom(features, out_rgb, width, height);
 }
 
 void orc_primary_hits(const orc_scene* scene, const orc_features* features, const orc_camera* camera, int width,

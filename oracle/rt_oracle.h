@@ -182,9 +182,10 @@ void orc_intersect_batch(const orc_scene* scene, const orc_features* features,
 
 /* renderImage (src/render.cpp:19-51).  out_rgb: width*height*3 floats in
  * Screen order, index (height-1-y)*width+x (src/screen.cpp:36-42).
- * threads <= 0: all OpenMP threads.  Returns 0, -1 for unsupported features
- * (motion blur; bloom filter sizes outside [3, 20], which the reference itself
- * cannot run without undefined behaviour). */
+ * threads <= 0: all OpenMP threads.  Returns 0, -1 for what it does not do
+ * (motion blur without depth of field: orc_render_motion_blur; bloom filter
+ * sizes outside [3, 20], which the reference itself cannot run without
+ * undefined behaviour). */
 /* postprocessImageWithBloom (src/extra.cpp:276-316) on a frame in Screen order,
  * in place; no-op when enableBloomEffect is off.  Returns 0, or -1 for a filter
  * size outside [3, 20]. */
@@ -197,6 +198,17 @@ void orc_bmp_bytes(const float* rgb, int width, int height, uint8_t* out);
 int orc_render(const orc_scene* scene, const orc_features* features,
                const orc_camera* camera, int width, int height, float* out_rgb,
                orc_stats* stats, int policy, int threads);
+
+/* renderImageWithMotionBlur (src/extra.cpp:121-211) + the bloom pass.  The
+ * reference rebuilds a BVH over a moved copy of the scene for every time sample
+ * of every pixel, from the meshes' triangles in the scene's own order:
+ * scene_order_prims holds them in that order (what was handed to orc_bvh_build,
+ * not what it returned).  The sum over the time samples starts at zero; the
+ * reference leaves it uninitialised.  Returns 0, -1 when motion blur is off or
+ * depth of field is on (renderImage then takes the other renderer). */
+int orc_render_motion_blur(const orc_scene* scene, const orc_primitive* scene_order_prims, uint32_t n_prims,
+                           const orc_features* features, const orc_camera* camera, int width, int height,
+                           float* out_rgb, orc_stats* stats, int threads);
 
 /* Pixel-centre primary rays of the given camera (src/render.cpp:68-69):
  * closest-hit primitive index and t per pixel, Screen order. */

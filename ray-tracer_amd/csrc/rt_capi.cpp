@@ -1087,8 +1087,8 @@ int rt_features_set(rt_ctx* ctx, const rt_features* f)
 try {
     if (!ctx || !f)
         return fail(ctx, RT_ERR_INVALID, "rt_features_set: NULL argument");
-    if (f->enableMotionBlur)
-        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_features_set: motion blur (renderImageWithMotionBlur) is outside this path");
+    if (f->enableMotionBlur && !f->enableDepthOfField && f->motionBlurSamples > 65535)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_features_set: %d motion blur samples", f->motionBlurSamples);
     if (f->enableBloomEffect && (f->bloomFilterSize < (uint32_t)kBloomMinSize || f->bloomFilterSize > (uint32_t)kBloomMaxSize))
         return fail(ctx, RT_ERR_UNSUPPORTED,
             "rt_features_set: bloomFilterSize %u: below %d the reference's filter loop writes outside the image, above %d its factorial overflows",
@@ -1123,6 +1123,9 @@ static void lcgJump(uint64_t k, uint32_t& mul, uint32_t& add)
     }
 }
 
+// renderImage takes the depth-of-field renderer when both are asked for (src/render.cpp:22-25)
+static bool motionBlurOn(const rt_features& f) { return f.enableMotionBlur && !f.enableDepthOfField; }
+
 static DevFeat makeFeat(const rt_features& f)
 {
     DevFeat d {};
@@ -1136,6 +1139,7 @@ static DevFeat makeFeat(const rt_features& f)
     d.dofDistance = f.depthOfFieldDistance, d.dofDiameter = f.depthOfFieldCircleDiameter, d.dofSamples = f.numDepthOfFieldSamples;
     d.divDof = makeFastDiv(std::max(1u, f.numDepthOfFieldSamples));
     d.maxDepth = f.maxRayDepth;
+    d.motion = motionBlurOn(f), d.motionSamples = f.motionBlurSamples, d.movement = f.movement;
     // src/render.cpp:58-70, :118: ray count and draws of the pixel-sample stretch
     d.jitterN = static_cast<uint32_t>(std::round(std::sqrt(static_cast<float>(f.numPixelSamples))));
     uint32_t drawsPerCamRay = 0;
@@ -1204,6 +1208,8 @@ static size_t traversalLds(const rt_ctx* ctx)
 static int perPixelVariant(const rt_features& F, bool collect)
 {
     int variant = 0;
+    if (motionBlurOn(F))
+        return 16 | 1 | 2 | (collect ? 8 : 0);
     if (F.enableTransparency)
         variant |= 1;
     if (F.enableGlossyReflection && F.enableReflections)
@@ -1394,7 +1400,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         && ctx->occ.variant == perPixelVariant(F, false);
     if (arena && !occReady)
         return fail(ctx, RT_ERR_STATE, "render: launch geometry not prepared (rt_scene_upload and rt_features_set do that)");
-    const bool perPixel = ctx->forcePerPixel || (F.enableGlossyReflection && F.enableReflections);
+    const bool perPixel = ctx->forcePerPixel || (F.enableGlossyReflection && F.enableReflections) || motionBlurOn(F);
     if (perPixel) {
         const int variant = perPixelVariant(F, collect);
         int perCU = ctx->blocksPerCU;

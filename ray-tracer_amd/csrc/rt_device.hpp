@@ -164,6 +164,9 @@ struct DevFeat {
     uint32_t dofSamples;
     FastDiv divDof; // by max(dofSamples, 1)
     int32_t maxDepth;
+    // renderImageWithMotionBlur (src/extra.cpp:121-211); taken only without depth of field (src/render.cpp:22-25)
+    int32_t motion, motionSamples;
+    float movement;
     // derived per frame
     uint32_t raysPerPixel, jitterN, camRays;
     // LCG jump constants: state after k draws = mul*seed + add
@@ -484,6 +487,74 @@ __device__ __forceinline__ bool sphereTest(const DevSphere& s, f3 o, f3 d, float
         return false;
     tOut = t;
     return true;
+}
+
+// ----------------------------------------------------------------------------
+// Motion blur (src/extra.cpp:121-211): every pixel sample draws a time and renders a copy of the
+// scene whose vertices and sphere centres have been moved by splineMat (src/extra.cpp:546-567).
+// A Mover holds what that move needs for one time; moved() is the move of one position, operation
+// for operation (the Bezier sum, glm::translate's column, the mat4 * vec4 product and the division
+// by w), so a moved vertex has the bits the reference's copy of the scene holds.
+// The control points are offset + position and the weights sum to one, so the move is, up to
+// rounding, position -> 2 * position + shift: the copy is twice the size of the scene.
+// ----------------------------------------------------------------------------
+struct Mover {
+    float w0, w1, w2, w3, w4; // weights of the five control points at this time
+    f3 c0, c1, c2, c3, c4;    // the control points' offsets, times `movement`
+    f3 shift;                 // sum of weight * offset: where the origin goes, to rounding
+};
+
+__device__ __forceinline__ Mover makeMover(float t, float movement)
+{
+    Mover m;
+    m.c0 = mk3(0.0f, 0.0f, 0.0f) * movement;
+    m.c1 = mk3(0.0f, 1.0f, 1.0f) * movement;
+    m.c2 = mk3(1.0f, 1.0f, -1.0f) * movement;
+    m.c3 = mk3(1.0f, 0.0f, 0.0f) * movement;
+    m.c4 = mk3(1.5f, 1.0f, 2.0f) * movement;
+    const float oneMinusT = 1.0f - t;
+    const float oneMinusTSquared = oneMinusT * oneMinusT;
+    const float tSquared = t * t;
+    const float tCubed = tSquared * t;
+    m.w0 = oneMinusTSquared * oneMinusTSquared;
+    m.w1 = 4.0f * oneMinusTSquared * oneMinusT * t;
+    m.w2 = 6.0f * oneMinusTSquared * tSquared;
+    m.w3 = 4.0f * oneMinusT * tCubed;
+    m.w4 = tSquared * tSquared;
+    m.shift = (m.w0 * m.c0) + (m.w1 * m.c1) + (m.w2 * m.c2) + (m.w3 * m.c3) + (m.w4 * m.c4);
+    return m;
+}
+
+__device__ __forceinline__ f3 moved(const Mover& m, f3 v)
+{
+    const f3 p0 = m.c0 + v, p1 = m.c1 + v, p2 = m.c2 + v, p3 = m.c3 + v, p4 = m.c4 + v;
+    const f3 b = (m.w0 * p0) + (m.w1 * p1) + (m.w2 * p2) + (m.w3 * p3) + (m.w4 * p4);
+    // glm::translate(mat4(1), b), ext/matrix_transform.inl:13: column 3 = m[0]*b.x + m[1]*b.y + m[2]*b.z + m[3]
+    const float tx = ((1.0f * b.x + 0.0f * b.y) + 0.0f * b.z) + 0.0f;
+    const float ty = ((0.0f * b.x + 1.0f * b.y) + 0.0f * b.z) + 0.0f;
+    const float tz = ((0.0f * b.x + 0.0f * b.y) + 1.0f * b.z) + 0.0f;
+    const float tw = ((0.0f * b.x + 0.0f * b.y) + 0.0f * b.z) + 1.0f;
+    // mat4 * vec4(v, 1), detail/type_mat4x4.inl:561-572: (m[0]*v.x + m[1]*v.y) + (m[2]*v.z + m[3]*1)
+    const float x = (1.0f * v.x + 0.0f * v.y) + (0.0f * v.z + tx * 1.0f);
+    const float y = (0.0f * v.x + 1.0f * v.y) + (0.0f * v.z + ty * 1.0f);
+    const float z = (0.0f * v.x + 0.0f * v.y) + (1.0f * v.z + tz * 1.0f);
+    const float w = (0.0f * v.x + 0.0f * v.y) + (0.0f * v.z + tw * 1.0f);
+    return { x / w, y / w, z / w };
+}
+
+// The plane and edge terms of a triangle from its three vertices, as the scene upload computes
+// them for the record (and as the reference's triangle routine computes them per test).
+__device__ __forceinline__ TriRec triFromVertices(f3 v0, f3 v1, f3 v2)
+{
+    TriRec r;
+    const f3 c = cross(v1 - v0, v2 - v0);
+    r.n = c * (1.0f / sqrtf(dot(c, c)));
+    r.D = dot(v0, r.n);
+    r.E0 = cross(v2 - v0, r.n);
+    r.E1 = cross(v0 - v1, r.n);
+    r.E2 = cross(v1 - v2, r.n);
+    r.v0 = v0, r.v1 = v1, r.v2 = v2;
+    return r;
 }
 
 // Conservative slab test.  The reference's box routine divides per axis and

@@ -18,6 +18,12 @@
 // rt_wavefront.hip instead, which spreads the rays of one pixel over many
 // lanes; both produce the same bits.
 //
+// Motion blur (src/extra.cpp:121-211) is a variant of this kernel only: the
+// reference renders every time sample of every pixel in a moved copy of the
+// whole scene with a tree built for that copy; here the lane keeps the rest
+// scene's tree and moves the vertices it meets (Tracer<., MOTION>), and the
+// loop over time samples wraps the loop over the pixel's camera rays.
+//
 // No MFMA: nothing here is a dense contraction.
 
 #include "rt_trace.hpp"
@@ -35,7 +41,7 @@ enum Phase : int {
 };
 enum FrameStage : int { FR_REFLECT = 0, FR_GLOSSY = 1, FR_TRANSP = 2 };
 
-constexpr int V_TRANSP = 1, V_GLOSSY = 2, V_DOF = 4, V_STATS = 8;
+constexpr int V_TRANSP = 1, V_GLOSSY = 2, V_DOF = 4, V_STATS = 8, V_MOTION = 16;
 
 // What renderRay keeps of its own hit while a child ray is traced
 // (src/recursive.cpp:36-61): Lo, the material terms the combine needs, and the
@@ -60,6 +66,9 @@ struct Lane {
     uint32_t rayI;
     f3 Lpix;
     f3 pof;
+    // motion blur: the sampler the times are drawn from, the time sample under way, the sum over them
+    uint32_t sTime, mi;
+    f3 Lmo;
     // the hit being shaded
     int depth;
     HitCtx h;
@@ -83,7 +92,7 @@ struct Shader {
     const DevCamera& cam;
     const DevFeat& ft;
     const DevFrame& fr;
-    const Tracer<(V & V_STATS) != 0>& tracer;
+    const Tracer<(V & V_STATS) != 0, (V & V_MOTION) != 0>& tracer;
     float* out;
     Frame* frames; // per-lane private arrays (scratch)
     GlossyFrame* gframes;
@@ -318,16 +327,57 @@ struct Shader {
         }
     }
 
+    // One time sample begins (src/extra.cpp:145-204): its time is the next draw of the pixel's sampler,
+    // and the sample is rendered with a copy of that sampler as it stands after the draw, so sample
+    // i + 1 sees the stream of sample i moved on by one.
+    __device__ __forceinline__ void beginMotionSample(Lane& L) const
+    {
+        const float time = next1d(L.sTime);
+        L.r.mv = makeMover(time, ft.movement);
+        L.sPix = L.sTime;
+        L.sMain = ft.mainMul * L.sTime + ft.mainAdd;
+        L.rayI = 0;
+        L.Lpix = mk3(0.0f);
+    }
+
+    // A pixel begins.  The sum over the time samples starts at zero here; the reference adds into a
+    // vector it never initialises (src/extra.cpp:144, :205).
+    __device__ __forceinline__ void beginMotionPixel(Lane& L, uint32_t seed) const
+    {
+        L.sTime = seed;
+        L.mi = 0;
+        L.Lmo = mk3(0.0f);
+        if (ft.motionSamples > 0) {
+            beginMotionSample(L);
+        } else { // no sample at all: 0 / samples, through the same code as the last sample of a pixel
+            L.rayI = ft.raysPerPixel;
+            L.Lpix = mk3(0.0f);
+            L.mi = 0xffffffffu;
+        }
+    }
+
     __device__ __forceinline__ void nextRay(Lane& L) const
     {
         if (L.rayI >= ft.raysPerPixel) {
-            const f3 c = L.Lpix / (float)ft.raysPerPixel; // src/recursive.cpp:16
-            const size_t idx = fr.packed ? (size_t)L.widx : ((size_t)(fr.height - 1 - L.py) * fr.width + L.px);
-            out[3 * idx + 0] = c.x;
-            out[3 * idx + 1] = c.y;
-            out[3 * idx + 2] = c.z;
-            L.phase = PH_NEWPIXEL;
-            return;
+            f3 c = L.Lpix / (float)ft.raysPerPixel; // src/recursive.cpp:16
+            bool done = true;
+            if (V & V_MOTION) { // src/extra.cpp:205-208
+                L.Lmo = L.Lmo + c;
+                L.mi++;
+                done = (int)L.mi >= ft.motionSamples;
+                if (done)
+                    c = L.Lmo / (float)ft.motionSamples;
+                else
+                    beginMotionSample(L);
+            }
+            if (done) {
+                const size_t idx = fr.packed ? (size_t)L.widx : ((size_t)(fr.height - 1 - L.py) * fr.width + L.px);
+                out[3 * idx + 0] = c.x;
+                out[3 * idx + 1] = c.y;
+                out[3 * idx + 2] = c.z;
+                L.phase = PH_NEWPIXEL;
+                return;
+            }
         }
         f3 o, d;
         cameraRay<(V & V_DOF) != 0>(cam, ft, fr, L.px, L.py, L.rayI, L.sPix, L.sLens, L.pof, o, d);
@@ -355,7 +405,7 @@ struct Shader {
                         L.value = sampleEnvironmentMap(sc, ft, L.r.d);
                         L.phase = PH_RETURN;
                     } else {
-                        L.h = shadeHit(sc, ft, L.r);
+                        L.h = shadeHit<(V & V_MOTION) != 0>(sc, ft, L.r);
                         L.rd = L.r.d;
                         L.li = 0;
                         L.si = 0;
@@ -395,7 +445,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void renderKernel(cons
     Frame frames[kMaxDepth + 1];
     GlossyFrame gframes[(V & V_GLOSSY) ? (kMaxDepth + 1) : 1];
 
-    const Tracer<(V & V_STATS) != 0> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
+    const Tracer<(V & V_STATS) != 0, (V & V_MOTION) != 0> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const Shader<V> shader { sc, cam, ft, fr, tracer, out, frames, gframes };
 
     Lane L;
@@ -461,6 +511,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void renderKernel(cons
                         L.rayI = 0;
                         L.Lpix = mk3(0.0f);
                         L.phase = PH_NEXTRAY;
+                        if (V & V_MOTION)
+                            shader.beginMotionPixel(L, seed);
                     }
                     // padding pixels of a partial edge tile are skipped: the lane stays in
                     // PH_NEWPIXEL and takes part in the next hand-out
@@ -668,6 +720,8 @@ static RenderFn renderVariant(int v)
 #ifdef RT_FAST_BUILD // experiments: only the plain and the counting variant
     return (v & 8) ? renderKernel<8> : renderKernel<0>;
 #endif
+    if (v & V_MOTION) // one variant for every feature set: motion blur is slow by what it asks for, not by dead branches
+        return (v & V_STATS) ? renderKernel<V_MOTION | V_TRANSP | V_GLOSSY | V_STATS> : renderKernel<V_MOTION | V_TRANSP | V_GLOSSY>;
     switch (v) {
     case 0: return renderKernel<0>;
     case 1: return renderKernel<1>;

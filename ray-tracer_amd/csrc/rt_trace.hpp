@@ -45,6 +45,7 @@ struct RayState {
     uint32_t itInner, itLeaf, itRuns; // counting builds: loop iterations this lane sat through
     uint32_t topHits[3];              // counting builds: inner steps at pair records below 1024 / 2048 / 4096
     unsigned long long cycInner, cycLeaf, cycRun; // counting builds: shader clocks spent in the two blocks and in run() as a whole
+    Mover mv; // motion blur only: the move of the scene copy this ray is traced in
 };
 
 __device__ __forceinline__ f3 rcp3(f3 d)
@@ -56,16 +57,25 @@ __device__ __forceinline__ f3 rcp3(f3 d)
 // (see Tracer::settleTie).  Out of line on purpose: it runs for one ray in millions and must not
 // weigh on the register budget of the loops that call it.  `stk` is the calling lane's column of
 // the LDS stack (entries `stride` words apart), empty by now; returns (closest t as bits, primitive or kHitNone).
+// With a Mover, the nodes and triangles are those of the moved copy of the scene: the move is monotone per
+// coordinate, so the box of a set of moved vertices is the moved box, and the copy's tree has the rest
+// tree's shape wherever the centroids keep their order (they do but for pairs a rounding apart).
 static __device__ __attribute__((noinline)) uint2 replayReference(const uint4* __restrict__ nodes, const float4* __restrict__ tris, LdsWords stk,
-    uint32_t stride, float ox, float oy, float oz, float dx, float dy, float dz, float tmax)
+    uint32_t stride, float ox, float oy, float oz, float dx, float dy, float dz, float tmax, const Mover* mv = nullptr)
 {
     const float o[3] = { ox, oy, oz }, d[3] = { dx, dy, dz };
     const f3 O = { ox, oy, oz }, D = { dx, dy, dz };
     int hitPrim = kHitNone;
     auto box = [&](uint32_t node, float& t) {
         const uint4 a = nodes[2u * node], b = nodes[2u * node + 1u];
-        const float lo[3] = { __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z) };
-        const float hi[3] = { __uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y) };
+        f3 l3 = { __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z) };
+        f3 h3 = { __uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y) };
+        if (mv) {
+            l3 = moved(*mv, l3);
+            h3 = moved(*mv, h3);
+        }
+        const float lo[3] = { l3.x, l3.y, l3.z };
+        const float hi[3] = { h3.x, h3.y, h3.z };
         t = kFltMax;
         return refBoxTest(lo, hi, o, d, t);
     };
@@ -82,7 +92,14 @@ static __device__ __attribute__((noinline)) uint2 replayReference(const uint4* _
             const uint32_t first = w.z & ~RT_LEAF_BIT;
             for (uint32_t i = first; i < first + w.w; i++) {
                 float t;
-                if (triangleTestLazy(tris + 6u * i, O, D, tmax, t)) {
+                bool hit;
+                if (mv) {
+                    const TriRec rest = loadTri(tris, i);
+                    hit = triangleTest(triFromVertices(moved(*mv, rest.v0), moved(*mv, rest.v1), moved(*mv, rest.v2)), O, D, tmax, t);
+                } else {
+                    hit = triangleTestLazy(tris + 6u * i, O, D, tmax, t);
+                }
+                if (hit) {
                     tmax = t;
                     hitPrim = (int)i;
                 }
@@ -104,7 +121,12 @@ static __device__ __attribute__((noinline)) uint2 replayReference(const uint4* _
     return make_uint2(__float_as_uint(tmax), (uint32_t)hitPrim);
 }
 
-template <bool STATS>
+// MOTION: every ray carries a Mover (RayState::mv) and meets the moved copy of the scene: the triangle
+// and sphere tests run on moved positions, computed on the spot, while the boxes stay the rest scene's.
+// Since the move is position -> 2 * position + shift up to a few roundings, a box test against the
+// moved box is a test of the ray (origin - shift) / 2, direction / 2 -- same distances along it --
+// against the rest box, widened by what those roundings can amount to.
+template <bool STATS, bool MOTION = false>
 struct Tracer {
     const DevScene& sc;
     int accel;
@@ -141,15 +163,29 @@ struct Tracer {
     }
 
     // The root box test of src/bvh.cpp:253-259: does the ray enter the scene's box at all?
-    __device__ __forceinline__ bool entersScene(f3 o, f3 inv) const
+    __device__ __forceinline__ bool entersScene(f3 o, f3 inv, float pad = 0.0f) const
     {
         float e;
-        const f3 lo = { sc.rootLo[0], sc.rootLo[1], sc.rootLo[2] }, hi = { sc.rootHi[0], sc.rootHi[1], sc.rootHi[2] };
+        const f3 lo = { sc.rootLo[0] - pad, sc.rootLo[1] - pad, sc.rootLo[2] - pad };
+        const f3 hi = { sc.rootHi[0] + pad, sc.rootHi[1] + pad, sc.rootHi[2] + pad };
         return sc.nPrims != 0 && boxTest(lo, hi, o, inv, kFltMax, e);
     }
 
+    // Motion blur: how far, in the rest scene's space, a moved position can lie from 2 * position + shift
+    // halved back.  The move is some twenty roundings of numbers no larger than the scene's largest
+    // coordinate plus twice the movement; 2^-18 of that bound leaves a factor of ten.
+    __device__ __forceinline__ float motionPad(const RayState& r) const
+    {
+        float big = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            big = fmaxf(big, fmaxf(fabsf(sc.rootLo[a]), fabsf(sc.rootHi[a])));
+        big += 2.0f * fmaxf(fmaxf(fabsf(r.mv.c4.x), fabsf(r.mv.c4.y)), fabsf(r.mv.c4.z));
+        return big * 3.814697265625e-6f; // 2^-18
+    }
+
     // Start the traversal at the root and set up the slab arithmetic of this ray.
-    __device__ __forceinline__ void enter(RayState& r, f3 inv) const
+    __device__ __forceinline__ void enter(RayState& r, f3 inv, f3 o, float pad = 0.0f) const
     {
         setCur(r, sc.rootRef);
         // t(q) = ((gridMin + q*cell) - o) * inv = q*A + B.  Rounding bound of the fused
@@ -160,11 +196,13 @@ struct Tracer {
         const f3 gmin = { sc.gridMin[0], sc.gridMin[1], sc.gridMin[2] };
         const f3 cell = { sc.gridCell[0], sc.gridCell[1], sc.gridCell[2] };
         f3 A = cell * inv;
-        const f3 B = (gmin - r.o) * inv;
+        const f3 B = (gmin - o) * inv;
         const float k = 9.5367431640625e-7f; // 2^-20
-        const f3 err = { (65535.0f * fabsf(A.x) + fabsf(B.x)) * k + 0.5005f * fabsf(A.x),
+        f3 err = { (65535.0f * fabsf(A.x) + fabsf(B.x)) * k + 0.5005f * fabsf(A.x),
             (65535.0f * fabsf(A.y) + fabsf(B.y)) * k + 0.5005f * fabsf(A.y),
             (65535.0f * fabsf(A.z) + fabsf(B.z)) * k + 0.5005f * fabsf(A.z) };
+        if (MOTION) // planes `pad` further out on either side
+            err = err + mk3(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z)) * (pad * 1.001f);
         const f3 C = 8388608.0f * A;
         f3 Bn = (B - err) - C, Bf = (B + err) - C;
         // An axis the ray (almost) does not move along: its slab places no bound.  That is
@@ -188,13 +226,23 @@ struct Tracer {
     {
         begin(r, o, d, tmax, kind);
         if (accel) {
-            const f3 inv = rcp3(d);
-            if (entersScene(o, inv))
-                enter(r, inv);
+            if (MOTION) {
+                const f3 inv = rcp3(d) * 2.0f;
+                const f3 oRest = (o - r.mv.shift) * 0.5f;
+                const float pad = motionPad(r);
+                if (entersScene(oRest, inv, pad))
+                    enter(r, inv, oRest, pad);
+            } else {
+                const f3 inv = rcp3(d);
+                if (entersScene(o, inv))
+                    enter(r, inv, o);
+            }
         } else {
             // enableAccelStructure off: every primitive in order (src/bvh.cpp:344-351)
             for (uint32_t i = 0; i < sc.nPrims; i++) {
-                const TriRec tr = loadTri(sc.tris, i);
+                TriRec tr = loadTri(sc.tris, i);
+                if (MOTION)
+                    tr = triFromVertices(moved(r.mv, tr.v0), moved(r.mv, tr.v1), moved(r.mv, tr.v2));
                 float t;
                 if (STATS)
                     r.nTris++;
@@ -210,7 +258,7 @@ struct Tracer {
     __device__ __forceinline__ void launchInside(RayState& r, f3 o, f3 d, float tmax, int kind) const
     {
         begin(r, o, d, tmax, kind);
-        enter(r, rcp3(d));
+        enter(r, rcp3(d), o);
     }
 
     // Conservative slab test against one quantised child box (three dwords, lo | hi << 16
@@ -348,7 +396,13 @@ struct Tracer {
         // A hierarchy of the library's own visits them in another order, so it decides by the index
         // for the time being, and the ray is marked: which of the two the reference tests later depends on
         // its own walk through the caller's tree, which settleTie() repeats once the traversal is over.
-        bool accept = triangleTestLazy(sc.tris + r.li, r.o, r.d, r.tmax, t);
+        bool accept;
+        if (MOTION) {
+            const TriRec rest = loadTri(sc.tris, r.li / 6u);
+            accept = triangleTest(triFromVertices(moved(r.mv, rest.v0), moved(r.mv, rest.v1), moved(r.mv, rest.v2)), r.o, r.d, r.tmax, t);
+        } else {
+            accept = triangleTestLazy(sc.tris + r.li, r.o, r.d, r.tmax, t);
+        }
         if (accept && t == r.tmax && r.hitPrim >= 0) {
             // (binary visibility asks for no primitive; a light sample under transparency looks at
             // nothing but the material of what it meets)
@@ -386,7 +440,8 @@ struct Tracer {
     __device__ __forceinline__ void settleTie(RayState& r) const
     {
         if (__builtin_expect(r.tie, 0) && sc.refNodes != nullptr && accel) {
-            const uint2 res = replayReference(sc.refNodes, sc.tris, stk, stride, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.slen);
+            const uint2 res = replayReference(sc.refNodes, sc.tris, stk, stride, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.slen,
+                MOTION ? &r.mv : nullptr);
             r.tmax = __uint_as_float(res.x);
             r.hitPrim = (int)res.y;
         }
@@ -399,7 +454,12 @@ struct Tracer {
     {
         for (int s = 0; s < sc.nSpheres; s++) {
             float t;
-            if (sphereTest(sc.spheres[s], r.o, r.d, r.tmax, t)) {
+            DevSphere sp = sc.spheres[s];
+            if (MOTION) { // src/extra.cpp:149-161
+                const f3 c = moved(r.mv, ld3(sp.center));
+                sp.center[0] = c.x, sp.center[1] = c.y, sp.center[2] = c.z;
+            }
+            if (sphereTest(sp, r.o, r.d, r.tmax, t)) {
                 r.tmax = t;
                 r.hitPrim = -2 - s;
             }
@@ -414,6 +474,7 @@ struct HitCtx {
     float shin, tr;
 };
 
+template <bool MOTION = false>
 __device__ __forceinline__ HitCtx shadeHit(const DevScene& sc, const DevFeat& ft, const RayState& r)
 {
     HitCtx h;
@@ -426,11 +487,18 @@ __device__ __forceinline__ HitCtx shadeHit(const DevScene& sc, const DevFeat& ft
         const float4 plane = sc.tris[6u * i];
         const float4 a3 = sc.attrs[4u * i + 3];
         m = sc.mats[__float_as_uint(a3.w)];
-        const f3 planeN = { plane.x, plane.y, plane.z };
+        f3 planeN = { plane.x, plane.y, plane.z };
+        TriRec tr;
+        if (MOTION) {
+            const TriRec rest = loadTri(sc.tris, i);
+            tr = triFromVertices(moved(r.mv, rest.v0), moved(r.mv, rest.v1), moved(r.mv, rest.v2));
+            planeN = tr.n;
+        }
         f3 N = planeN;
         f2 uv = { 0.0f, 0.0f };
         if (ft.normalInterp || ft.texMapping) {
-            const TriRec tr = loadTri(sc.tris, i);
+            if (!MOTION)
+                tr = loadTri(sc.tris, i);
             const float4 a0 = sc.attrs[4u * i + 0], a1 = sc.attrs[4u * i + 1], a2 = sc.attrs[4u * i + 2];
             // computeBarycentricCoord, src/interpolate.cpp:13-24
             const f3 n = cross(tr.v1 - tr.v0, tr.v2 - tr.v0);
@@ -453,7 +521,7 @@ __device__ __forceinline__ HitCtx shadeHit(const DevScene& sc, const DevFeat& ft
     } else {
         const DevSphere s = sc.spheres[-2 - r.hitPrim];
         m = sc.mats[s.material];
-        h.N = normalize(h.P - ld3(s.center));
+        h.N = normalize(h.P - (MOTION ? moved(r.mv, ld3(s.center)) : ld3(s.center)));
         h.kd = ld3(m.kd);
     }
     h.mkd = ld3(m.kd);

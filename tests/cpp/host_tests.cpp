@@ -125,6 +125,37 @@ static void renderAgainstOracle()
     std::vector<float> ref(size_t(W) * H * 3);
     orc_stats st;
     CHECK(orc_render(os, &of, &oc, W, H, ref.data(), &st, 0, 0) == 0);
+
+    // renderImageWithMotionBlur through the same entry (src/render.cpp:24-25, src/extra.cpp:121-211); the
+    // oracle builds a tree per time sample, from the triangles in the order the meshes hold them
+    {
+        Features blur = f;
+        blur.numPixelSamples = 1;
+        blur.extra.enableMotionBlur = true;
+        blur.extra.motionBlurSamples = 2;
+        blur.extra.movement = 0.4f;
+        const int w = 32, h = 24;
+        Screen moving(ivec2(w, h));
+        renderImage(scene, bvh, blur, camera, moving);
+        std::vector<orc_primitive> sceneOrder;
+        for (uint32_t m = 0; m < scene.meshes.size(); m++) {
+            for (const uvec3& t : scene.meshes[m].triangles) {
+                orc_primitive q;
+                static_assert(sizeof(orc_vertex) == sizeof(Vertex));
+                q.meshID = m;
+                std::memcpy(&q.v0, &scene.meshes[m].vertices[t.x], sizeof(Vertex));
+                std::memcpy(&q.v1, &scene.meshes[m].vertices[t.y], sizeof(Vertex));
+                std::memcpy(&q.v2, &scene.meshes[m].vertices[t.z], sizeof(Vertex));
+                sceneOrder.push_back(q);
+            }
+        }
+        const rt_features cb = detail::toC(blur);
+        orc_features ob;
+        std::memcpy(&ob, &cb, sizeof ob);
+        std::vector<float> want(size_t(w) * h * 3);
+        CHECK(orc_render_motion_blur(os, sceneOrder.data(), uint32_t(sceneOrder.size()), &ob, &oc, w, h, want.data(), nullptr, 0) == 0);
+        CHECK(std::memcmp(want.data(), moving.pixels().data(), want.size() * sizeof(float)) == 0);
+    }
     orc_scene_destroy(os);
     double maxAbs = 0, sum = 0;
     const float* got = reinterpret_cast<const float*>(screen.pixels().data());
@@ -163,12 +194,13 @@ static void renderAgainstOracle()
         std::filesystem::remove(bmp);
     }
 
-    // error behaviour: unsupported features throw, like the reference's loaders do
-    Features blur = f;
-    blur.extra.enableMotionBlur = true;
+    // error behaviour: what the library refuses throws, like the reference's loaders do
+    Features wide = f;
+    wide.extra.enableBloomEffect = true;
+    wide.extra.bloomFilterSize = 21; // the reference's factorial overflows there
     bool threw = false;
     try {
-        renderImage(scene, bvh, blur, camera, screen);
+        renderImage(scene, bvh, wide, camera, screen);
     } catch (const std::exception&) {
         threw = true;
     }

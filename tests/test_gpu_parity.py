@@ -635,7 +635,8 @@ def test_error_behaviour(ctx):
     with pytest.raises(capi.RtError) as e:
         fresh.render(sio.default_camera(8, 8), 8, 8)
     assert e.value.code == -4  # no features
-    for bad in (dict(enableMotionBlur=1), dict(enableBloomEffect=1, bloomFilterSize=2), dict(enableBloomEffect=1, bloomFilterSize=21)):
+    for bad in (dict(enableMotionBlur=1, motionBlurSamples=70000), dict(enableBloomEffect=1, bloomFilterSize=2),
+                dict(enableBloomEffect=1, bloomFilterSize=21)):
         with pytest.raises(capi.RtError) as e:
             fresh.set_features(common.features(**bad))
         assert e.value.code == -2
