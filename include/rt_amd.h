@@ -220,13 +220,15 @@ const char* rt_last_error(const rt_ctx* ctx);
 int rt_bvh_build(const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_node* nodes_out,
                  rt_primitive* prims_out, uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves);
 
-/* The same constructor with its work on the GPU of `ctx` (median split only; with sah_binning != 0 this is
- * rt_bvh_build): the tree's shape follows from n alone under the split at (n + 1) / 2 and is laid out on the
- * host; boxes and the per-node sorts by centroid (src/bvh.cpp:208-223) run level by level on the device.  Same
- * node and primitive arrays as rt_bvh_build, bit for bit: a range in which two centroid coordinates are equal
+/* The same constructor with its work on the GPU of `ctx`.  Median split: the tree's shape follows from n alone
+ * under the split at (n + 1) / 2 and is laid out on the host; boxes and the per-node sorts by centroid
+ * (src/bvh.cpp:208-223) run level by level on the device.  A range in which two centroid coordinates are equal
  * has no unique sorted arrangement (the reference's sort is not stable), so such ranges are sorted once more by
  * the host's std::sort from the arrangement they had; host_sorted (optional) receives how many primitives
- * went that way.  Host pointers in and out, like rt_bvh_build. */
+ * went that way.  sah_binning != 0: splitPrimitivesBySAHBin (src/extra.cpp:493-543) on the device -- buckets,
+ * the cost of every split position, the first cheapest one -- with the host only collecting the split positions
+ * of a level to lay out the next.  Either way the node and primitive arrays are rt_bvh_build's, bit for bit.
+ * Host pointers in and out, like rt_bvh_build. */
 int rt_bvh_build_device(rt_ctx* ctx, const rt_primitive* prims_in, uint32_t n, int sah_binning, rt_node* nodes_out,
                         rt_primitive* prims_out, uint32_t* n_nodes, uint32_t* n_levels, uint32_t* n_leaves,
                         uint32_t* host_sorted);

@@ -21,6 +21,16 @@
 // sorted again on the host, from the arrangement they had before, by the very
 // std::sort call the host builder uses.  Meshes from a modelling tool rarely have
 // such ranges; a box of axis-aligned quads has little else and is tiny.
+//
+// The other builder, Features::extra.enableBvhSahBinning (splitPrimitivesBySAHBin,
+// src/extra.cpp:493-543), is here too (deviceSahBinBuild).  There the split position
+// of a node depends on the data, so the shape of the tree is only known level by
+// level: per level the device buckets every range into the reference's eleven
+// buckets (a stable sort, like its bucket-by-bucket copy: no ties to worry about),
+// evaluates its cost at every position of every range (prefix and suffix boxes by a
+// blocked scan; min and max are exact in any order) and reports the first cheapest
+// position per range; the host turns those into the next level's ranges, and at the
+// end numbers the nodes the way the recursion would have.
 
 #include <hip/hip_runtime.h>
 
@@ -38,7 +48,7 @@ namespace rt {
 namespace {
 
 struct Seg {
-    uint32_t begin, count, node, inner; // range of primitive positions, node index, 1 = the node is split
+    uint32_t begin, count, node, inner; // range of primitive positions, node index, 1 = the node is split, 2 = a leaf finished on an earlier level
 };
 
 constexpr uint32_t kPrimWords = sizeof(rt_primitive) / 4; // 25
@@ -86,12 +96,17 @@ __global__ __launch_bounds__(256) void iotaKernel(uint32_t* order, uint32_t n)
 // their arrangement (their keys are the positions).
 __global__ __launch_bounds__(256) void levelKernel(const Seg* __restrict__ segs, const uint32_t* __restrict__ order, uint32_t n,
     const float* __restrict__ lo, const float* __restrict__ hi, const float* __restrict__ c, rt_node* __restrict__ nodes,
-    unsigned long long* __restrict__ keys, float* __restrict__ keyf)
+    unsigned long long* __restrict__ keys, float* __restrict__ keyf, int buckets)
 {
     __shared__ float red[6][256];
     __shared__ uint32_t at[6][256];
     __shared__ int axisShared;
     const Seg s = segs[blockIdx.x];
+    if (s.inner == 2u) { // its box was made when it became a leaf; it only has to keep its place in the sort
+        for (uint32_t k = threadIdx.x; k < s.count; k += blockDim.x)
+            keys[s.begin + k] = ((unsigned long long)blockIdx.x << 32) | k;
+        return;
+    }
     // The reference folds the boxes in the order of the range with std::min / std::max, which keep what they have
     // when the next value is equal: the result is the value that came FIRST among equal ones -- which matters for
     // nothing but the sign of a zero, and the node records are compared bit for bit.  So every partial result
@@ -141,13 +156,27 @@ __global__ __launch_bounds__(256) void levelKernel(const Seg* __restrict__ segs,
     }
     __syncthreads();
     const int axis = axisShared;
+    // splitPrimitivesBySAHBin's bucket of a centroid, src/extra.cpp:501-506 (ten bins' width, eleven buckets; a
+    // quotient that is negative or not a number, which is undefined there, goes to bucket 0, one beyond the last
+    // bucket to the last)
+    const float axisLo = red[axis][0];
+    const float binSize = (red[3 + axis][0] - axisLo) / 10.0f;
     for (uint32_t k = threadIdx.x; k < s.count; k += blockDim.x) {
         const uint32_t p = s.begin + k;
         uint32_t low = k;
         if (s.inner) {
             const float f = c[(size_t)axis * n + order[p]];
-            keyf[p] = f;
-            low = orderable(f);
+            if (buckets) {
+                const float q = floorf((f - axisLo) / binSize);
+                uint32_t b = 0;
+                if (q >= 0.0f)
+                    b = q >= 10.0f ? 10u : (uint32_t)q;
+                keyf[p] = (float)b;
+                low = b;
+            } else {
+                keyf[p] = f;
+                low = orderable(f);
+            }
         }
         keys[p] = ((unsigned long long)blockIdx.x << 32) | low;
     }
@@ -279,7 +308,7 @@ __global__ __launch_bounds__(256) void smallSortKernel(const Seg* __restrict__ s
     uint32_t* __restrict__ order, uint32_t* __restrict__ flags, uint32_t* __restrict__ any)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nSegs || !segs[s].inner)
+    if (s >= nSegs || segs[s].inner != 1u)
         return;
     const uint32_t b = segs[s].begin, cnt = segs[s].count;
     bool tie = false;
@@ -303,6 +332,101 @@ __global__ __launch_bounds__(256) void smallSortKernel(const Seg* __restrict__ s
         flags[s] = 1u;
         *any = 1u;
     }
+}
+
+// computeSurfaceArea, src/extra.cpp:476-483
+__device__ __forceinline__ float boxArea(const float* b)
+{
+    const float x = b[3] - b[0], y = b[4] - b[1], z = b[5] - b[2];
+    return 2.0f * (x * y + x * z + y * z);
+}
+__device__ __forceinline__ void boxMerge(float* b, const float* o)
+{
+    for (int a = 0; a < 3; a++) {
+        b[a] = (o[a] < b[a]) ? o[a] : b[a];
+        b[3 + a] = (b[3 + a] < o[3 + a]) ? o[3 + a] : b[3 + a];
+    }
+}
+
+// The cost loop of splitPrimitivesBySAHBin (src/extra.cpp:519-542) for every split range of a level, one block
+// per range, on the bucketed arrangement: cost of position i = i * area(box of the first i primitives) +
+// (m - i) * area(box of the primitives AFTER the i-th) -- the right-hand box lags one primitive behind its
+// count, as in the reference -- for i in [1, m - 2]; the first cheapest position is the split.  Every thread
+// owns a stretch of the range; the boxes before and after a stretch come from the other threads' stretch boxes.
+__global__ __launch_bounds__(256) void sahSplitKernel(const Seg* __restrict__ segs, const uint32_t* __restrict__ order, uint32_t n,
+    const float* __restrict__ lo, const float* __restrict__ hi, float* __restrict__ costLeft, uint32_t* __restrict__ splits)
+{
+    __shared__ float part[256][6];
+    __shared__ float bestCost[256];
+    __shared__ uint32_t bestAt[256];
+    __shared__ int firstIsNaN;
+    const Seg s = segs[blockIdx.x];
+    if (s.inner != 1u)
+        return;
+    const uint32_t m = s.count, stretch = (m + 255u) / 256u;
+    const uint32_t kb = min(threadIdx.x * stretch, m), ke = min(kb + stretch, m);
+    const float inf = __builtin_inff();
+    auto primBox = [&](uint32_t k, float* b) {
+        const uint32_t i = order[s.begin + k];
+        for (uint32_t a = 0; a < 3; a++)
+            b[a] = lo[(size_t)a * n + i], b[3 + a] = hi[(size_t)a * n + i];
+    };
+    float mine[6] = { inf, inf, inf, -inf, -inf, -inf };
+    for (uint32_t k = kb; k < ke; k++) {
+        float b[6];
+        primBox(k, b);
+        boxMerge(mine, b);
+    }
+    for (int q = 0; q < 6; q++)
+        part[threadIdx.x][q] = mine[q];
+    if (threadIdx.x == 0)
+        firstIsNaN = 0;
+    __syncthreads();
+    float before[6] = { inf, inf, inf, -inf, -inf, -inf }, after[6] = { inf, inf, inf, -inf, -inf, -inf };
+    for (uint32_t t = 0; t < 256u; t++) {
+        if (t < threadIdx.x)
+            boxMerge(before, part[t]);
+        else if (t > threadIdx.x)
+            boxMerge(after, part[t]);
+    }
+    // left to right: the box of everything before position k
+    for (uint32_t k = kb; k < ke; k++) {
+        if (k >= 1u && k + 2u <= m)
+            costLeft[s.begin + k] = (float)k * boxArea(before);
+        float b[6];
+        primBox(k, b);
+        boxMerge(before, b);
+    }
+    // right to left: the box of everything after position k; going down, an equal cost at a lower position wins
+    float best = 0.0f;
+    uint32_t at = 0xffffffffu;
+    for (uint32_t k = ke; k > kb; k--) {
+        const uint32_t kk = k - 1u;
+        if (kk >= 1u && kk + 2u <= m) {
+            const float cost = costLeft[s.begin + kk] + (float)(m - kk) * boxArea(after);
+            if (kk == 1u && cost != cost)
+                firstIsNaN = 1; // the reference's running minimum starts here and nothing compares below it
+            if (cost == cost && (at == 0xffffffffu || cost <= best))
+                best = cost, at = kk;
+        }
+        float b[6];
+        primBox(kk, b);
+        boxMerge(after, b);
+    }
+    bestCost[threadIdx.x] = best;
+    bestAt[threadIdx.x] = at;
+    __syncthreads();
+    for (uint32_t w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) {
+            const uint32_t oa = bestAt[threadIdx.x + w], ma = bestAt[threadIdx.x];
+            const float oc = bestCost[threadIdx.x + w], mc = bestCost[threadIdx.x];
+            if (oa != 0xffffffffu && (ma == 0xffffffffu || oc < mc || (oc == mc && oa < ma)))
+                bestCost[threadIdx.x] = oc, bestAt[threadIdx.x] = oa;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        splits[blockIdx.x] = (firstIsNaN || bestAt[0] == 0xffffffffu) ? 1u : bestAt[0];
 }
 
 __global__ __launch_bounds__(256) void gatherPrimsKernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ order, uint32_t n,
@@ -445,14 +569,14 @@ bool deviceMedianBuild(const rt_primitive* in, uint32_t n, rt_node* nodesOut, rt
                 maxCount = std::max(maxCount, s.count), inners++;
         BUILD_TRY(hipMemcpyAsync(dSegs, segs.data(), nSegs * sizeof(Seg), hipMemcpyHostToDevice, 0));
         if (inners == 0) { // a level of leaves: boxes only
-            hipLaunchKernelGGL(levelKernel, dim3(nSegs), dim3(256), 0, 0, dSegs, dOrder[cur], n, dLo, dHi, dC, dNodes, dKeys[cur], dKeyf);
+            hipLaunchKernelGGL(levelKernel, dim3(nSegs), dim3(256), 0, 0, dSegs, dOrder[cur], n, dLo, dHi, dC, dNodes, dKeys[cur], dKeyf, 0);
             continue;
         }
         BUILD_TRY(hipMemsetAsync(dFlags, 0, nSegs * sizeof(uint32_t), 0));
         BUILD_TRY(hipMemsetAsync(dAny, 0, sizeof(uint32_t), 0));
         BUILD_TRY(hipMemcpyAsync(dOrderPrev, dOrder[cur], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, 0));
         if (maxCount <= 64) {
-            hipLaunchKernelGGL(levelKernel, dim3(nSegs), dim3(256), 0, 0, dSegs, dOrder[cur], n, dLo, dHi, dC, dNodes, dKeys[cur], dKeyf);
+            hipLaunchKernelGGL(levelKernel, dim3(nSegs), dim3(256), 0, 0, dSegs, dOrder[cur], n, dLo, dHi, dC, dNodes, dKeys[cur], dKeyf, 0);
             hipLaunchKernelGGL(smallSortKernel, dim3((nSegs + 255) / 256), dim3(256), 0, 0, dSegs, nSegs, dKeyf, dOrder[cur], dFlags, dAny);
         } else {
             // Ranges this large only exist while every node of the level above was split, so they tile the whole
@@ -465,7 +589,7 @@ bool deviceMedianBuild(const rt_primitive* in, uint32_t n, rt_node* nodesOut, rt
                 }
                 at += s.count;
             }
-            hipLaunchKernelGGL(levelKernel, dim3(nSegs), dim3(256), 0, 0, dSegs, dOrder[cur], n, dLo, dHi, dC, dNodes, dKeys[cur], dKeyf);
+            hipLaunchKernelGGL(levelKernel, dim3(nSegs), dim3(256), 0, 0, dSegs, dOrder[cur], n, dLo, dHi, dC, dNodes, dKeys[cur], dKeyf, 0);
             uint32_t segBits = 0;
             while ((1u << segBits) < nSegs)
                 segBits++;
@@ -526,6 +650,159 @@ bool deviceMedianBuild(const rt_primitive* in, uint32_t n, rt_node* nodesOut, rt
     std::copy(nodes.begin(), nodes.end(), nodesOut);
     if (stats)
         stats->levels = static_cast<uint32_t>(levels.size());
+    return true;
+}
+
+bool deviceSahBinBuild(const rt_primitive* in, uint32_t n, rt_node* nodesOut, rt_primitive* primsOut, uint32_t* nNodes,
+    uint32_t* nLevels, uint32_t* nLeaves, DeviceBuildStats* stats, std::string& error)
+{
+    if (stats)
+        *stats = DeviceBuildStats {};
+    if (n <= 4) { // a single leaf (or the empty tree): nothing is split, the median builder's tree is this builder's
+        return deviceMedianBuild(in, n, nodesOut, primsOut, nNodes, nLevels, nLeaves, stats, error);
+    }
+    // Nodes get provisional numbers in the order the levels create them; the recursion's numbers follow at the end.
+    struct Prov {
+        uint32_t begin, count, left, right, level; // left == 0: a leaf
+    };
+    std::vector<Prov> prov { { 0u, n, 0u, 0u, 0u } };
+    std::vector<Seg> segs { { 0u, n, 0u, 1u } }, next;
+
+    DeviceBuffers buf;
+    uint32_t *dPrims, *dPrimsOut, *dOrder[2], *dHist, *dSplits, *dFlags, *dAny;
+    float *dLo, *dHi, *dC, *dKeyf, *dCost;
+    unsigned long long* dKeys[2];
+    rt_node* dNodes;
+    Seg* dSegs;
+    const uint32_t nBlocks = (n + kSortTile - 1) / kSortTile;
+    BUILD_TRY(buf.get(&dPrims, (size_t)n * kPrimWords));
+    BUILD_TRY(buf.get(&dPrimsOut, (size_t)n * kPrimWords));
+    BUILD_TRY(buf.get(&dOrder[0], n));
+    BUILD_TRY(buf.get(&dOrder[1], n));
+    BUILD_TRY(buf.get(&dKeys[0], n));
+    BUILD_TRY(buf.get(&dKeys[1], n));
+    BUILD_TRY(buf.get(&dKeyf, n));
+    BUILD_TRY(buf.get(&dCost, n));
+    BUILD_TRY(buf.get(&dLo, (size_t)3 * n));
+    BUILD_TRY(buf.get(&dHi, (size_t)3 * n));
+    BUILD_TRY(buf.get(&dC, (size_t)3 * n));
+    BUILD_TRY(buf.get(&dHist, (size_t)256 * nBlocks));
+    BUILD_TRY(buf.get(&dSplits, n));
+    BUILD_TRY(buf.get(&dFlags, n));
+    BUILD_TRY(buf.get(&dAny, 1));
+    BUILD_TRY(buf.get(&dNodes, (size_t)2 * n)); // a tree over n primitives has at most 2n - 1 nodes
+    BUILD_TRY(buf.get(&dSegs, n));              // and a level at most n ranges
+    BUILD_TRY(hipMemcpy(dPrims, in, (size_t)n * sizeof(rt_primitive), hipMemcpyHostToDevice));
+    const uint32_t grid = (n + 255) / 256;
+    hipLaunchKernelGGL(primInfoKernel, dim3(grid), dim3(256), 0, 0, dPrims, n, dLo, dHi, dC);
+    hipLaunchKernelGGL(iotaKernel, dim3(grid), dim3(256), 0, 0, dOrder[0], n);
+    int cur = 0;
+    std::vector<uint32_t> splits;
+    uint32_t levelsDone = 0;
+    for (;;) {
+        const uint32_t nSegs = static_cast<uint32_t>(segs.size());
+        uint32_t maxCount = 0, inners = 0, fresh = 0;
+        for (const Seg& s : segs) {
+            if (s.inner == 1u)
+                maxCount = std::max(maxCount, s.count), inners++;
+            if (s.inner != 2u)
+                fresh++;
+        }
+        if (fresh == 0)
+            break;
+        levelsDone++;
+        BUILD_TRY(hipMemcpyAsync(dSegs, segs.data(), nSegs * sizeof(Seg), hipMemcpyHostToDevice, 0));
+        hipLaunchKernelGGL(levelKernel, dim3(nSegs), dim3(256), 0, 0, dSegs, dOrder[cur], n, dLo, dHi, dC, dNodes, dKeys[cur], dKeyf, 1);
+        next.clear();
+        if (inners == 0) { // the last level: boxes of the leaves only
+            for (Seg& s : segs)
+                s.inner = 2u;
+            continue;
+        }
+        if (maxCount <= 64) { // one lane per range: an insertion sort on the bucket numbers is stable
+            hipLaunchKernelGGL(smallSortKernel, dim3((nSegs + 255) / 256), dim3(256), 0, 0, dSegs, nSegs, dKeyf, dOrder[cur], dFlags, dAny);
+        } else { // the bucket digit, then the range number: ranges tile the array in order, finished leaves included
+            uint32_t segBits = 0;
+            while ((1u << segBits) < nSegs)
+                segBits++;
+            const uint32_t passes = 1 + (segBits + 7) / 8;
+            for (uint32_t p = 0; p < passes; p++) {
+                const uint32_t shift = p == 0 ? 0u : 32u + 8u * (p - 1);
+                hipLaunchKernelGGL(radixCountKernel, dim3(nBlocks), dim3(256), 0, 0, dKeys[cur], n, shift, dHist, nBlocks);
+                hipLaunchKernelGGL(exclusiveScanKernel, dim3(1), dim3(1024), 0, 0, dHist, 256u * nBlocks);
+                hipLaunchKernelGGL(radixScatterKernel, dim3(nBlocks), dim3(256), 0, 0, dKeys[cur], dOrder[cur], dKeys[cur ^ 1], dOrder[cur ^ 1], n,
+                    shift, dHist, nBlocks);
+                cur ^= 1;
+            }
+        }
+        hipLaunchKernelGGL(sahSplitKernel, dim3(nSegs), dim3(256), 0, 0, dSegs, dOrder[cur], n, dLo, dHi, dCost, dSplits);
+        BUILD_TRY(hipGetLastError());
+        splits.resize(nSegs);
+        BUILD_TRY(hipMemcpy(splits.data(), dSplits, nSegs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < nSegs; i++) {
+            const Seg& s = segs[i];
+            if (s.inner != 1u) {
+                next.push_back({ s.begin, s.count, s.node, 2u });
+                continue;
+            }
+            const uint32_t split = splits[i];
+            if (split < 1u || split + 2u > s.count) {
+                error = "device build: a split position outside its range";
+                return false;
+            }
+            const uint32_t left = static_cast<uint32_t>(prov.size()), level = prov[s.node].level + 1;
+            prov[s.node].left = left, prov[s.node].right = left + 1;
+            prov.push_back({ s.begin, split, 0u, 0u, level });
+            prov.push_back({ s.begin + split, s.count - split, 0u, 0u, level });
+            next.push_back({ s.begin, split, left, split > 4u ? 1u : 0u });
+            next.push_back({ s.begin + split, s.count - split, left + 1, s.count - split > 4u ? 1u : 0u });
+        }
+        segs.swap(next);
+    }
+    const size_t words = (size_t)n * kPrimWords;
+    hipLaunchKernelGGL(gatherPrimsKernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, 0, dPrims, dOrder[cur], n, dPrimsOut);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(hipMemcpy(primsOut, dPrimsOut, words * 4, hipMemcpyDeviceToHost));
+    std::vector<rt_node> boxes(prov.size());
+    BUILD_TRY(hipMemcpy(boxes.data(), dNodes, prov.size() * sizeof(rt_node), hipMemcpyDeviceToHost));
+
+    // ---- the recursion's numbering (src/bvh.cpp:424-493): a node's children take the next two indices when the
+    // node is reached, depth first, left subtree before the right one; index 1 is the unused node (src/bvh.cpp:88-89)
+    std::vector<rt_node> nodes(2);
+    std::memset(nodes.data(), 0, 2 * sizeof(rt_node));
+    nodes[1].upper[0] = nodes[1].upper[1] = nodes[1].upper[2] = 1.0f;
+    struct Visit {
+        uint32_t prov, index;
+    };
+    std::vector<Visit> work { { 0u, 0u } };
+    uint32_t leaves = 0, deepest = 0;
+    while (!work.empty()) {
+        const Visit v = work.back();
+        work.pop_back();
+        const Prov& pn = prov[v.prov];
+        rt_node nd = boxes[v.prov];
+        deepest = std::max(deepest, pn.level);
+        if (pn.left == 0u) {
+            nd.data[0] = pn.begin | RT_LEAF_BIT;
+            nd.data[1] = pn.count;
+            leaves++;
+        } else {
+            const uint32_t left = static_cast<uint32_t>(nodes.size());
+            nodes.emplace_back();
+            nodes.emplace_back();
+            nd.data[0] = left;
+            nd.data[1] = left + 1;
+            work.push_back({ pn.right, left + 1 });
+            work.push_back({ pn.left, left });
+        }
+        nodes[v.index] = nd;
+    }
+    std::copy(nodes.begin(), nodes.end(), nodesOut);
+    *nNodes = static_cast<uint32_t>(nodes.size());
+    *nLevels = deepest + 1;
+    *nLeaves = leaves;
+    if (stats)
+        stats->levels = levelsDone;
     return true;
 }
 

@@ -19,4 +19,9 @@ struct DeviceBuildStats {
 bool deviceMedianBuild(const rt_primitive* in, uint32_t n, rt_node* nodesOut, rt_primitive* primsOut, uint32_t* nNodes,
     uint32_t* nLevels, uint32_t* nLeaves, DeviceBuildStats* stats, std::string& error);
 
+// The same with splitPrimitivesBySAHBin (src/extra.cpp:493-543) as the split; same outputs as rt_bvh_build with
+// sah_binning set, bit for bit.
+bool deviceSahBinBuild(const rt_primitive* in, uint32_t n, rt_node* nodesOut, rt_primitive* primsOut, uint32_t* nNodes,
+    uint32_t* nLevels, uint32_t* nLeaves, DeviceBuildStats* stats, std::string& error);
+
 } // namespace rt

@@ -760,12 +760,12 @@ try {
         return fail(ctx, RT_ERR_INVALID, "rt_bvh_build_device: NULL argument");
     if (host_sorted)
         *host_sorted = 0;
-    if (sah_binning) // the split position of that builder depends on the data at every node: host code for now
-        return rt_bvh_build(prims_in, n, sah_binning, nodes_out, prims_out, n_nodes, n_levels, n_leaves);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DeviceBuildStats st;
     std::string err;
-    if (!deviceMedianBuild(prims_in, n, nodes_out, prims_out, n_nodes, n_levels, n_leaves, &st, err))
+    const bool ok = sah_binning ? deviceSahBinBuild(prims_in, n, nodes_out, prims_out, n_nodes, n_levels, n_leaves, &st, err)
+                                : deviceMedianBuild(prims_in, n, nodes_out, prims_out, n_nodes, n_levels, n_leaves, &st, err);
+    if (!ok)
         return fail(ctx, RT_ERR_DEVICE, "rt_bvh_build_device: %s", err.c_str());
     if (host_sorted)
         *host_sorted = st.primitivesSortedOnHost;

@@ -768,6 +768,55 @@ def test_device_bvh_build_equals_the_oracles(ctx, name):
     assert (len(nodes), len(out), leaves, levels) == shape
 
 
+@pytest.mark.parametrize("name", ["SingleTriangle", "Cube", "CornellBox", "Monkey", "Teapot", "Dragon"])
+def test_device_sah_binned_bvh_build_equals_the_oracles(ctx, name):
+    """The same with Features::extra.enableBvhSahBinning: splitPrimitivesBySAHBin (src/extra.cpp:493-543) decides every
+    split on the GPU (buckets, cost of every position, first cheapest), and the arrays are the oracle's and
+    rt_bvh_build's bit for bit.  Parity unpinned against the reference: its tests hold no tree of this builder."""
+    import time
+    prims = common.scene(name).primitives()
+    t0 = time.perf_counter()
+    nodes, out, levels, leaves, host_sorted = ctx.bvh_build_device(prims, sah_binning=True)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n_h, p_h, l_h, f_h = capi.bvh_build(prims, True)
+    t_host = time.perf_counter() - t0
+    n_o, p_o, l_o, f_o = orc.bvh_build(prims, True)
+    print(f"{name}: {len(prims)} primitives, {levels} levels, device build {t_dev * 1e3:.1f} ms, host build {t_host * 1e3:.1f} ms")
+    assert host_sorted == 0
+    assert (levels, leaves) == (l_o, f_o) == (l_h, f_h)
+    assert nodes.tobytes() == n_o.tobytes() == n_h.tobytes()
+    assert out.tobytes() == p_o.tobytes() == p_h.tobytes()
+
+
+def test_device_sah_binned_bvh_build_edge_cases(ctx):
+    # all centroids equal (no extent along any axis: every quotient 0/0, everything in bucket 0), a lattice soup
+    # with equal costs at many positions and negative zeros, and a long thin strip (a deep, lopsided tree)
+    p = np.zeros(37, dtype=sio.PRIMITIVE)
+    p["v1"]["position"] = (1, 0, 0)
+    p["v2"]["position"] = (0, 1, 0)
+    p["meshID"] = np.arange(37)
+    cases = [p[:3], p[:5], p[:9], p]
+    rng = np.random.default_rng(1)
+    q = np.zeros(20000, dtype=sio.PRIMITIVE)
+    for v in ("v0", "v1", "v2"):
+        q[v]["position"] = (rng.integers(-6, 7, (len(q), 3)) * 0.25).astype(np.float32)
+    q["v0"]["position"][::7] *= np.float32(-0.0)
+    q["meshID"] = np.arange(len(q)) % 5
+    cases.append(q)
+    strip = np.zeros(3000, dtype=sio.PRIMITIVE)
+    x = (np.arange(3000, dtype=np.float32) ** np.float32(1.7)).astype(np.float32)
+    strip["v0"]["position"] = np.stack([x, np.zeros_like(x), np.zeros_like(x)], 1)
+    strip["v1"]["position"] = np.stack([x + 1, np.zeros_like(x), np.zeros_like(x)], 1)
+    strip["v2"]["position"] = np.stack([x, np.ones_like(x), rng.random(3000, dtype=np.float32)], 1)
+    cases.append(strip)
+    for c in cases:
+        nodes, out, levels, leaves, _ = ctx.bvh_build_device(c, sah_binning=True)
+        n_o, p_o, l_o, f_o = orc.bvh_build(c, True)
+        assert (levels, leaves) == (l_o, f_o), len(c)
+        assert nodes.tobytes() == n_o.tobytes() and out.tobytes() == p_o.tobytes(), len(c)
+
+
 def test_device_bvh_build_edge_cases(ctx):
     # nothing at all; fewer primitives than a leaf holds; all centroids equal (every range goes to the host's sort)
     nodes, out, levels, leaves, _ = ctx.bvh_build_device(np.zeros(0, dtype=sio.PRIMITIVE))
