@@ -24,7 +24,7 @@ rendezvous over gloo, "render" their tiles of a synthetic frame on the CPU,
 gather, de-interleave, reduce the timings like the real run, and rank 0 prints
 one JSON line with the ranks the collective library saw.
 
-Frames in flight: consecutive steps go round-robin to `--in-flight` (default 3, 4 when N > 1) contexts, each
+Frames in flight: consecutive steps go round-robin to `--in-flight` (default 3; 4 at N = 2, 6 from N = 4) contexts, each
 with its own stream, workspace and output buffers, the way a double- or triple-buffered
 renderer runs.  Every frame is still rendered, gathered and post-processed completely; the
 persistent traversal kernels of one frame merely start on the compute units the previous
@@ -286,9 +286,10 @@ def main():
     if args.camera_distance != 3.0:
         desc += f" [camera distance {args.camera_distance} instead of the default 3.0]"
 
-    # three at N = 1 (measured: four and five frames in flight are no faster at the headline size);
-    # four on a shard, where the fixed part of a frame weighs more
-    lanes = args.in_flight if args.in_flight > 0 else (3 if world == 1 else 4)
+    # three at N = 1 (measured: four to six frames in flight are no faster at the headline size); more on a
+    # shard, where the fixed part of a frame weighs more (an eighth of the frame, eight hardware queues:
+    # 0.92 ms a frame with three, 0.86 with four, 0.85 with six; half the frame: no difference)
+    lanes = args.in_flight if args.in_flight > 0 else (3 if world == 1 else (4 if world < 4 else 6))
     stride = capi.shard_floats(width, height, 0, world)
     ctxs, streams, frames, packeds, gathereds = [], [], [], [], []
     for _ in range(lanes):

@@ -25,6 +25,8 @@ dist.barrier = lambda *a, **k: None
 dist.destroy_process_group = lambda *a, **k: None
 dist.all_reduce = lambda t, op=None: None  # MAX and SUM over one answering rank: unchanged
 dist.gather = gather
+dist.get_world_size = lambda *a, **k: world
+torch.cuda.device_count = lambda: world  # bench.py checks that the node has a GPU per rank; rank 0 only ever uses device 0
 sys.argv = ["bench.py", "--gpus", str(world)] + sys.argv[2:]
 import bench  # noqa: E402
 
