@@ -191,8 +191,9 @@ void rt_ctx_destroy(rt_ctx* ctx);
  *  RT_OPT_PER_PIXEL         1 = every frame on the kernel that walks a pixel in renderRay's own depth-first
  *                           order (the only one for glossy reflections); 0 (default) = queue-based renderer.
  *  RT_OPT_STRICT_INTERSECT  1 = rt_intersect_batch replays every ray in the reference's own order of box
- *                           and triangle tests (src/bvh.cpp:245-316), also reproducing the hits the
- *                           reference's box routine loses by rounding for rays aimed exactly at vertices.
+ *                           and triangle tests (src/bvh.cpp:245-316).  A cross-check: by default only rays
+ *                           are replayed that met equal distances, or whose hit the reference's box routine
+ *                           (which loses hits by rounding) may have kept it from; the answers are the same.
  *  RT_OPT_WORKSPACE_BYTES   cap on the working memory of the queue-based renderer (default 64 GiB, never more
  *                           than the device has free); a frame that needs more is rendered in pixel batches.
  *  RT_OPT_TIMING            0 = record no events around the render launches (rt_stats times read 0).

@@ -82,6 +82,7 @@ struct rt_ctx {
     uint4* dPairs = nullptr;
     bool strictIntersect = false; // rt_intersect_batch replays every ray in the reference's order of tests
     uint4* dRefNodes = nullptr; // the caller's nodes as they came (replay of the reference's order of tests)
+    float4* dLeafBoxes = nullptr; // per primitive, the box of the caller's leaf that holds it (Tracer::surelyReached)
     uint32_t numPairs = 0; // pair records in dPairs
     float4* dTris = nullptr;
     float4* dAttrs = nullptr;
@@ -366,7 +367,7 @@ void rt_ctx_destroy(rt_ctx* ctx)
         return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = { ctx->dPairs, ctx->dRefNodes, ctx->dTris, ctx->dAttrs, ctx->dMats, ctx->dTexs, ctx->dTexels, ctx->dSpheres, ctx->dLights,
+    void* ptrs[] = { ctx->dPairs, ctx->dRefNodes, ctx->dLeafBoxes, ctx->dTris, ctx->dAttrs, ctx->dMats, ctx->dTexs, ctx->dTexels, ctx->dSpheres, ctx->dLights,
         ctx->dCounters, ctx->dFrame, ctx->dBloom };
     for (void* p : ptrs)
         if (p)
@@ -924,6 +925,18 @@ try {
         rootRef = (r0.data[0] & RT_LEAF_BIT) ? (kLeafFlag | (r0.data[1] << 27) | (r0.data[0] & ~RT_LEAF_BIT)) : 0u;
     }
 
+    // per primitive, the box of the caller's leaf that holds it (Tracer::surelyReached): lower.xyz upper.x | upper.yz 0 0
+    std::vector<float4> leafBoxes(static_cast<size_t>(n_prims) * 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (!seen[i] || !(nodes[i].data[0] & RT_LEAF_BIT))
+            continue;
+        const uint32_t first = nodes[i].data[0] & ~RT_LEAF_BIT;
+        for (uint32_t k = 0; k < nodes[i].data[1]; k++) {
+            leafBoxes[2 * static_cast<size_t>(first + k)] = make_float4(nodes[i].lower[0], nodes[i].lower[1], nodes[i].lower[2], nodes[i].upper[0]);
+            leafBoxes[2 * static_cast<size_t>(first + k) + 1] = make_float4(nodes[i].upper[1], nodes[i].upper[2], 0.0f, 0.0f);
+        }
+    }
+
     std::vector<float4> tris(static_cast<size_t>(n_prims) * 6), attrs(static_cast<size_t>(n_prims) * 4);
     for (uint32_t i = 0; i < n_prims; i++) {
         const rt_primitive& q = prims[i];
@@ -1010,6 +1023,7 @@ try {
     }
     if (replayable)
         maxLevel = std::max(maxLevel, callerLevels);
+    HIP_TRY(ctx, uploadVec(&ctx->dLeafBoxes, leafBoxes));
     HIP_TRY(ctx, uploadVec(&ctx->dTris, tris));
     HIP_TRY(ctx, uploadVec(&ctx->dAttrs, attrs));
     HIP_TRY(ctx, uploadVec(&ctx->dMats, mats));
@@ -1039,6 +1053,7 @@ try {
     s.nPrims = n_prims;
     s.tieByIndex = (ownTree && ctx->treeMode == 2) ? 1 : 0;
     s.refNodes = replayable ? ctx->dRefNodes : nullptr;
+    s.leafBoxes = ctx->dLeafBoxes;
     s.strictIntersect = ctx->strictIntersect ? 1 : 0;
     s.nMeshes = static_cast<int32_t>(n_meshes);
     s.nSpheres = static_cast<int32_t>(n_spheres);
@@ -1475,7 +1490,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             shadowPerCU = std::min(ctx->forceShadowPerCU, maxPerCU);
         // per light sample: its contribution (12 B) and its ray, 32 B; with transparency the ray record also
         // carries the light's colour (48 B) and a visibility byte goes with it
-        const uint64_t perItem = transp ? (12ull + 48 + 1) : (12ull + 32);
+        // (without it, four bytes for the list of samples the replay has to decide)
+        const uint64_t perItem = transp ? (12ull + 48 + 1) : (12ull + 32 + 4);
         const uint64_t perNodeBytes = 64 + sizeof(NodeB) + perItem * std::max(1u, slots);
         // node slots a wavefront of the path kernel reserves at a time; from a fixed arena the smallest
         // the kernel knows, and only as many path blocks as keep the unused ends of those blocks within
@@ -1560,7 +1576,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, slots);
             const size_t w[10] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
                 F.enableEnvironmentMap ? static_cast<size_t>(paths) * 12 : 16, static_cast<size_t>(maxNodes) * 64,
-                static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * (transp ? 48 : 32), transp ? items : 16,
+                static_cast<size_t>(maxNodes) * sizeof(NodeB), items * 12, items * (transp ? 48 : 32), transp ? items : items * 4,
                 static_cast<size_t>(queued) * 32 };
             size_t total = 0;
             for (int i = 0; i < 10; i++)
@@ -1623,6 +1639,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         wb.contrib = static_cast<float*>(ws[6]);
         wb.srays = static_cast<float4*>(ws[7]);
         wb.svis = static_cast<uint8_t*>(ws[8]);
+        wb.redo = static_cast<uint32_t*>(ws[8]);
         wb.camRays = static_cast<float4*>(ws[9]);
         wb.maxNodes = static_cast<uint32_t>(maxNodes);
 
@@ -1688,6 +1705,8 @@ static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
     DevCounters& c = *ctx->hostCounters;
     const bool debug = getenv("RT_AMD_DEBUG_COUNTERS") != nullptr;
     HIP_TRY(ctx, hipMemcpy(&c, ctx->lastCounters, debug ? sizeof c : offsetof(DevCounters, waveLog), hipMemcpyDeviceToHost));
+    if (debug)
+        fprintf(stderr, "[rt_amd] light samples of the last batch left to the replay (their occluder's leaf may be out of the reference's reach): %u\n", c.redo.v);
     if (getenv("RT_AMD_DEBUG_COUNTERS") && (c.loopIters[0][2] | c.loopIters[1][2])) {
         // wave iterations of the traversal loop and the mean number of lanes that had work in them
         const char* names[2] = { "path", "shadow" };

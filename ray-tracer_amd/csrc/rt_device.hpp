@@ -141,10 +141,11 @@ struct DevScene {
     // upper, data[2]); only read when a ray has to be replayed in the reference's order of tests
     // (Tracer::settleTie).  Null when the caller's tree is deeper than a lane's stack.
     const uint4* refNodes;
-    // rt_intersect_batch only: replay every ray that way (RT_OPT_STRICT_INTERSECT).  The reference's own box
-    // test is not conservative: a ray aimed exactly at a vertex or at the corner of a leaf's box can
-    // miss, by rounding, a box that holds its hit, and the reference then reports the next hit or none,
-    // where the traversal here (whose box tests never lose a hit) reports the nearer one.
+    // Per primitive, the box of the caller's leaf that holds it (two 16-B words: lower.xyz upper.x | upper.yz 0 0):
+    // what Tracer::surelyReached asks the reference's box routine about.
+    const float4* leafBoxes;
+    // rt_intersect_batch only: replay every ray that way (RT_OPT_STRICT_INTERSECT), not only those that
+    // Tracer::settleTie picks out (equal distances; a hit the reference's box routine may have lost).
     int32_t strictIntersect;
 };
 
@@ -203,6 +204,7 @@ struct DevCounters {
     // work-queue heads, the node allocator, the number of queued camera rays, and the flags the first
     // wave to find a queue empty raises for the others ([0] path, [1] shadow); cleared before every batch
     HotCounter next, nextShadow, nodes, camQueued, dry[2];
+    HotCounter redo; // light samples whose occluder the reference may not have come to (Tracer::surelyReached): entries of WfBuffers::redo
     // counting launches only: iterations of the traversal loop summed over all 64 lanes of
     // every wave (divide by 64 for wave iterations), [0] inner [1] leaf [2] calls of run()
     unsigned long long loopIters[2][3]; // [0] path kernel, [1] shadow kernel
@@ -562,18 +564,37 @@ __device__ __forceinline__ TriRec triFromVertices(f3 v0, f3 v1, f3 v2)
 // decides which nodes are visited and in which order, never the hit itself.
 // Here the slabs use one subtract and one multiply by 1/d per plane and the
 // interval is widened by a few ulp, so a box is never skipped that the exact
-// test would have entered.  A NaN slab (0 * inf) drops out of min/max, which
-// reproduces "ignore that axis".  Returns the entry distance clamped to 0.
+// test would have entered.  Returns the entry distance clamped to 0.
 constexpr float kPadLo = 1.0f - 4.76837158e-7f; // 1 - 2^-21
 constexpr float kPadHi = 1.0f + 4.76837158e-7f; // 1 + 2^-21
 
-__device__ __forceinline__ bool boxTest(f3 lo, f3 hi, f3 o, f3 inv, float tmax, float& entry)
+// 1/d for the box tests: an infinite one (a direction component of zero) is held to +-1e18.  The ray then
+// counts as creeping along that axis: planes on either side of it lie at -+(distance) * 1e18, far beyond any real t,
+// so a box the ray's plane does not pass through is turned away as it should be; a plane the origin lies exactly IN
+// lies at zero, where infinity would have made "0 * inf" of it and lost the ray, and the additive widening of the
+// tests (proportional to |1/d|) takes it from there.  Leaving such an axis out altogether, as the reference does,
+// is conservative too, but lets a ray that runs along an axis into every box it passes above or below: a single
+// lane then walks thousands of boxes while its kernel waits (measured: seven such rays in the headline frame
+// doubled the path kernel's time).
+__device__ __forceinline__ f3 boundedRcp(f3 inv)
 {
+    return { __builtin_amdgcn_fmed3f(inv.x, -1.0e18f, 1.0e18f), __builtin_amdgcn_fmed3f(inv.y, -1.0e18f, 1.0e18f),
+        __builtin_amdgcn_fmed3f(inv.z, -1.0e18f, 1.0e18f) };
+}
+
+__device__ __forceinline__ bool boxTest(f3 lo, f3 hi, f3 o, f3 invIn, float tmax, float& entry)
+{
+    const f3 inv = boundedRcp(invIn);
     const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
     const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
     const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
-    const float tIn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f)) * kPadLo;
-    const float tOut = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kPadHi;
+    // additive part of the widening: 2^-20 of the coordinates involved, as a distance along the ray
+    const float k = 9.5367431640625e-7f;
+    const float px = fabsf(inv.x) * ((fabsf(lo.x) + fabsf(hi.x) + fabsf(o.x)) * k);
+    const float py = fabsf(inv.y) * ((fabsf(lo.y) + fabsf(hi.y) + fabsf(o.y)) * k);
+    const float pz = fabsf(inv.z) * ((fabsf(lo.z) + fabsf(hi.z) + fabsf(o.z)) * k);
+    const float tIn = fmaxf(fmaxf(fminf(ax, bx) - px, fminf(ay, by) - py), fmaxf(fminf(az, bz) - pz, 0.0f)) * kPadLo;
+    const float tOut = fminf(fminf(fmaxf(ax, bx) + px, fmaxf(ay, by) + py), fmaxf(az, bz) + pz) * kPadHi;
     entry = tIn;
     return tIn <= tOut && tIn <= tmax;
 }

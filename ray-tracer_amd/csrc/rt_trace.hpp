@@ -185,9 +185,10 @@ struct Tracer {
     }
 
     // Start the traversal at the root and set up the slab arithmetic of this ray.
-    __device__ __forceinline__ void enter(RayState& r, f3 inv, f3 o, float pad = 0.0f) const
+    __device__ __forceinline__ void enter(RayState& r, f3 invIn, f3 o, float pad = 0.0f) const
     {
         setCur(r, sc.rootRef);
+        const f3 inv = boundedRcp(invIn); // (a zero direction component: see there)
         // t(q) = ((gridMin + q*cell) - o) * inv = q*A + B.  Rounding bound of the fused
         // form: (|q*A| + |B|) * 2^-22 for the inputs plus half an ulp of the result;
         // (extent*|inv| + |B|) * 2^-20 covers it with room to spare.  Moving 2^23 * A
@@ -205,9 +206,7 @@ struct Tracer {
             err = err + mk3(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z)) * (pad * 1.001f);
         const f3 C = 8388608.0f * A;
         f3 Bn = (B - err) - C, Bf = (B + err) - C;
-        // An axis the ray (almost) does not move along: its slab places no bound.  That is
-        // what the reference's box routine does for a zero component, and for a huge 1/d it
-        // only means a few more boxes visited.
+        // What is still out of range after that (a direction that is not a number): the slab places no bound.
         const bool okx = fabsf(A.x) < 1.0e30f && fabsf(B.x) < 1.0e30f, oky = fabsf(A.y) < 1.0e30f && fabsf(B.y) < 1.0e30f,
                    okz = fabsf(A.z) < 1.0e30f && fabsf(B.z) < 1.0e30f;
         r.A = { okx ? A.x : 0.0f, oky ? A.y : 0.0f, okz ? A.z : 0.0f };
@@ -437,8 +436,45 @@ struct Tracer {
     // edge-sharing primitives), so the marked ray is simply traced again the reference's way; the
     // closest t is the same, the primitive is the reference's.  Call when the traversal has ended
     // and before the spheres.
+    // The other thing that takes the reference's own walk to decide: its box routine is not conservative.  It
+    // divides per plane and compares the quotients as they round, so a ray that starts on a face of a box and
+    // leaves it, or grazes an edge, can be turned away from a box whose primitive it does hit -- and the
+    // reference then reports the next hit, or none.  The traversal here never loses a hit; so once it has
+    // one, it asks whether the reference would have come to the leaf that holds it.  Boxes nest and every
+    // operation of the routine is monotone, so the reference reaches a leaf whenever its routine lets the ray
+    // into the leaf's own box at a distance above zero (at zero -- a ray that starts on the box -- the boxes
+    // around it may decide otherwise: doubtful).  Nearly every hit is cleared at once: its point lies inside
+    // the leaf's box, and when it does so by a margin far above any rounding, every quotient the routine forms
+    // lies on the right side of the hit's own distance.  The rest (a hit at a vertex that is a corner of the
+    // box; a triangle that lies IN a face of the box, as in axis-aligned scenes) gets the routine itself on that
+    // one box, and a ray it turns away there is settled by the replay.
+    __device__ __forceinline__ bool surelyReached(const RayState& r) const
+    {
+        const float4 b0 = sc.leafBoxes[2u * (uint32_t)r.hitPrim], b1 = sc.leafBoxes[2u * (uint32_t)r.hitPrim + 1u];
+        f3 lo = { b0.x, b0.y, b0.z }, hi = { b0.w, b1.x, b1.y };
+        if (MOTION) {
+            lo = moved(r.mv, lo);
+            hi = moved(r.mv, hi);
+        }
+        const f3 td = r.tmax * r.d;
+        const f3 X = r.o + td;
+        const float k = 3.814697265625e-6f; // 2^-18
+        const float mx = (fabsf(r.o.x) + fabsf(td.x) + fabsf(lo.x) + fabsf(hi.x)) * k;
+        const float my = (fabsf(r.o.y) + fabsf(td.y) + fabsf(lo.y) + fabsf(hi.y)) * k;
+        const float mz = (fabsf(r.o.z) + fabsf(td.z) + fabsf(lo.z) + fabsf(hi.z)) * k;
+        // (written so that a value that is not a number anywhere answers "not sure")
+        if (lo.x + mx < X.x && X.x < hi.x - mx && lo.y + my < X.y && X.y < hi.y - my && lo.z + mz < X.z && X.z < hi.z - mz)
+            return true;
+        const float l3[3] = { lo.x, lo.y, lo.z }, h3[3] = { hi.x, hi.y, hi.z };
+        const float o3[3] = { r.o.x, r.o.y, r.o.z }, d3[3] = { r.d.x, r.d.y, r.d.z };
+        float t = kFltMax;
+        return refBoxTest(l3, h3, o3, d3, t) && t > 0.0f;
+    }
+
     __device__ __forceinline__ void settleTie(RayState& r) const
     {
+        if (accel && sc.refNodes != nullptr && r.hitPrim >= 0 && !r.tie && !surelyReached(r))
+            r.tie = true;
         if (__builtin_expect(r.tie, 0) && sc.refNodes != nullptr && accel) {
             const uint2 res = replayReference(sc.refNodes, sc.tris, stk, stride, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.slen,
                 MOTION ? &r.mv : nullptr);

@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
 #ifdef RT_PATH_WAVES // experiments: force the register budget of this many waves per SIMD
 #define RT_PATH_ATTR __attribute__((amdgpu_waves_per_eu(RT_PATH_WAVES, RT_PATH_WAVES)))
 #else
-#define RT_PATH_ATTR
+// (four waves per SIMD is what the kernel's registers allowed before the check of Tracer::surelyReached came to
+// sit in its shading path; held to that, it keeps them for two spilled registers outside the loops)
+#define RT_PATH_ATTR __attribute__((amdgpu_waves_per_eu(STATS ? 1 : 4)))
 #endif
 template <bool STATS, bool TRANSP>
 __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
@@ -705,6 +707,8 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR RT_SHADOW_TRANSP_ATTR
                 }
             }
         }
+        if (TRANSP && have && !r.active && !r.tie && r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && !tracer.surelyReached(r))
+            r.tie = true; // the reference's own boxes may have kept it from this hit: same way out as a tie
         if (TRANSP && have && !r.active && r.tie) {
                 // Two materials met at exactly the same distance: which of them the reference keeps takes
                 // its own walk through the caller's tree (Tracer::settleTie).  Not here, where a call would
@@ -723,8 +727,15 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR RT_SHADOW_TRANSP_ATTR
                 // src/light.cpp:101-107
                 const bool visible = (r.hitPrim == kHitNone) ? true : (fabsf(r.tmax - r.slen) <= 0.0001f);
                 if (!visible) {
-                    float* dst = wb.contrib + 3u * (size_t)item;
-                    dst[0] = dst[1] = dst[2] = 0.0f;
+                    // An occluder the reference's own box tests may have kept it from (Tracer::surelyReached) proves
+                    // nothing: the sample goes on a list and shadowRedoKernel follows it the reference's way.
+                    // (A visible sample needs no such care: what the reference finds is among what was found here.)
+                    if (r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && !tracer.surelyReached(r)) {
+                        wb.redo[atomicAdd(&ctr->redo.v, 1u)] = item;
+                    } else {
+                        float* dst = wb.contrib + 3u * (size_t)item;
+                        dst[0] = dst[1] = dst[2] = 0.0f;
+                    }
                 }
                 have = false;
             } else { // src/light.cpp:138-150
@@ -856,6 +867,34 @@ __device__ __attribute__((noinline)) void redoTransparentSample(const DevScene& 
     if (extra) {
         atomicAdd(&ctr->rays, extra);
         atomicAdd(&ctr->sRays, extra);
+    }
+}
+
+// Without transparency: the light samples the traversal kernel would not decide (their occluder lies in a leaf the
+// reference's own box tests may have turned the ray away from), each traced again in the reference's own order
+// of tests over the caller's nodes; src/light.cpp:101-107 on that result.  A handful per frame, if any.
+__global__ __launch_bounds__(256) void shadowRedoKernel(const DevScene sc, const WfBuffers wb, DevCounters* __restrict__ ctr)
+{
+    __shared__ uint32_t redoStack[kMaxStack * 256];
+    const uint32_t n = ctr->redo.v;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t item = wb.redo[k];
+        const float4* sr = wb.srays + 2u * (size_t)item;
+        const float4 a = sr[0], b = sr[1];
+        const f3 o = { a.x, a.y, a.z }, d = { b.x, b.y, b.z };
+        const uint2 res = replayReference(sc.refNodes, sc.tris, (LdsWords)(redoStack + threadIdx.x), 256u, o.x, o.y, o.z, d.x, d.y, d.z, a.w);
+        float t = __uint_as_float(res.x);
+        bool hit = (int)res.y != kHitNone;
+        for (int s = 0; s < sc.nSpheres; s++) { // src/bvh.cpp:354-355
+            float ts;
+            if (sphereTest(sc.spheres[s], o, d, t, ts))
+                t = ts, hit = true;
+        }
+        const bool visible = !hit || fabsf(t - a.w) <= 0.0001f;
+        if (!visible) {
+            float* dst = wb.contrib + 3u * (size_t)item;
+            dst[0] = dst[1] = dst[2] = 0.0f;
+        }
     }
 }
 
@@ -1103,6 +1142,8 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, in
         (void)hipEventRecord(marks[2], stream);
     if (transp) // (otherwise the samples were shaded when they were generated)
         hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
+    else if (ft.shadows && ft.accel && sc.refNodes != nullptr)
+        hipLaunchKernelGGL(shadowRedoKernel, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr);
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
     const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
     if (transp)

@@ -36,7 +36,8 @@ struct WfBuffers {
     NodeB* nodeB;        // [nodes]
     float* contrib;      // [nodes * slots * 3]
     float4* srays;       // [nodes * slots * 3] shadow ray: origin.xyz length | direction.xyz 0 | light colour.xyz 0
-    uint8_t* svis;       // [nodes * slots]     1 = light sample visible
+    uint8_t* svis;       // [nodes * slots]     1 = light sample visible (transparency only)
+    uint32_t* redo;      // [nodes * slots]     without transparency, in svis' place: samples to be decided by the replay (shadowRedoKernel)
     float4* camRays;     // [paths*2] camera rays that need tracing: origin.xyz path(bits) | direction.xyz enters-the-scene-box flag
     uint32_t maxNodes;
 };

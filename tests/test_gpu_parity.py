@@ -491,39 +491,42 @@ def test_triangle_soup_with_degenerate_and_repeated_triangles():
         assert maxabs <= 2e-5 and rmse <= 2e-6, (env, maxabs)
 
 
-def test_rays_aimed_at_vertices_in_strict_mode():
+def test_rays_aimed_at_vertices_get_the_references_answer():
     """The reference's box test is not conservative: a ray aimed exactly at a vertex (which is also a corner
     of its leaf's box) can miss that box by rounding, and the reference then reports a farther hit or
-    none.  The traversal never loses a hit, so on such rays it differs from the reference by design
-    (half a per cent of such rays on the Cornell box, a tenth when many of them also run along an axis;
-    none of the rays of the frames compared).  With
-    RT_OPT_STRICT_INTERSECT set, rt_intersect_batch replays every ray in the reference's own order of tests
-    (the routine that settles equal-distance hits) and must agree on all of them."""
-    scn = common.scene("CornellBox")
-    osc = orc.OracleScene(scn)
-    P = np.stack([osc.prims["v0"]["position"], osc.prims["v1"]["position"], osc.prims["v2"]["position"]], axis=1).astype(np.float32)
-    rng = np.random.default_rng(0)
-    n = 30000
-    target = P[rng.integers(0, len(P), n), rng.integers(0, 3, n)]
-    o = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
-    d = target - o
-    rays = np.zeros(n, dtype=sio.RAY)
-    rays["origin"], rays["t"] = o, common.FLT_MAX
-    rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
-    f = common.features()
-    r_o, h_o, _ = osc.intersect(f, rays)
+    none (half a per cent of such rays on the Cornell box).  The traversal never loses a hit; what keeps it
+    the reference's answer is the question it asks of every hit it is about to report -- would the
+    reference's own box routine have let the ray into the leaf that holds it (Tracer::surelyReached) -- with
+    a replay in the reference's order of tests for every ray the quick form of that question cannot clear.
+    So rt_intersect_batch agrees with the oracle on every such ray, with and without
+    RT_OPT_STRICT_INTERSECT (which replays every ray, whatever the question says), under every tree."""
     differ = {}
-    for strict in (1, 0):
-        c = _ctx_with(strict_intersect=strict)
-        c.upload_scene(scn)
-        c.set_features(f)
-        r_g, h_g = c.intersect(rays)
-        c.close()
-        differ[strict] = int(((h_o["hit"] != h_g["hit"]) | (r_o["t"].view(np.uint32) != r_g["t"].view(np.uint32))
-                              | (h_o["primitive"] != h_g["primitive"])).sum())
-    print(f"rays aimed at vertices: {differ[0]} of {n} differ from the reference's answer by default, {differ[1]} in strict mode")
-    assert differ[1] == 0
-    assert differ[0] > 0  # (if this ever fails the reference's box test has become conservative: drop the mode)
+    for name, n in (("CornellBox", 30000), ("Cube", 20000), ("Teapot", 30000)):
+        scn = common.scene(name)
+        osc = orc.OracleScene(scn)
+        P = np.stack([osc.prims["v0"]["position"], osc.prims["v1"]["position"], osc.prims["v2"]["position"]], axis=1).astype(np.float32)
+        rng = np.random.default_rng(0)
+        target = P[rng.integers(0, len(P), n), rng.integers(0, 3, n)]
+        o = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+        o[::5] = P[rng.integers(0, len(P), len(o[::5])), rng.integers(0, 3, len(o[::5]))]  # from vertex to vertex: origins on box faces
+        d = target - o
+        d[(d == 0).all(axis=1)] = (1, 0, 0)
+        rays = np.zeros(n, dtype=sio.RAY)
+        rays["origin"], rays["t"] = o, common.FLT_MAX
+        rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        f = common.features()
+        r_o, h_o, _ = osc.intersect(f, rays)
+        assert h_o["hit"].any() and not h_o["hit"].all()
+        for strict, tree in ((1, 2), (0, 2), (0, 1), (0, 0)):
+            c = _ctx_with(strict_intersect=strict, tree=tree)
+            c.upload_scene(scn)
+            c.set_features(f)
+            r_g, h_g = c.intersect(rays)
+            c.close()
+            differ[(name, strict, tree)] = int(((h_o["hit"] != h_g["hit"]) | (r_o["t"].view(np.uint32) != r_g["t"].view(np.uint32))
+                                                | (h_o["primitive"] != h_g["primitive"])).sum())
+    print("rays aimed at vertices that differ from the reference's answer (scene, strict, tree):", differ)
+    assert not any(differ.values())
 
 
 def test_sampler_stream_and_texcoord_interpolation_on_the_device(ctx):

@@ -1,0 +1,96 @@
+"""Seeded random walks through the feature space: every draw is a scene, a set of lights, a camera and a
+Features value the reference's GUI could be clicked into (src/main.cpp:200-330), rendered on the device and by
+the oracle at a small size.  Ray counts must be equal and the frames within the stated tolerance (2e-5 max abs);
+the combinations no hand-written test names are what this is for (bloom on a jittered depth-of-field frame,
+an environment map behind transparent mirrors under a segment light, motion blur with textures, ...)."""
+import copy
+import importlib
+
+import numpy as np
+import pytest
+
+import common
+from common import sio
+
+pytestmark = pytest.mark.gpu
+
+capi = importlib.import_module("ray-tracer_amd.capi")
+import orc  # noqa: E402
+
+SCENES = ["CornellBox", "CornellBoxTransparency", "CornellBoxParallelogramLight", "CubeTextured", "Monkey", "Cube", "Spheres"]
+
+
+def _draw(rng):
+    name = SCENES[rng.integers(len(SCENES))]
+    env = bool(rng.integers(2))
+    scn = copy.deepcopy(common.scene(name, env_map=env))
+    # materials: now and then a mirror, a gloss, a see-through mesh
+    for m in scn.meshes:
+        if rng.random() < 0.3:
+            m.material["ks"] = tuple(rng.random(3).astype(np.float32) * np.float32(0.8))
+            m.material["shininess"] = float(rng.integers(1, 60))
+        if rng.random() < 0.25:
+            m.material["transparency"] = float(np.float32(rng.choice([0.3, 0.5, 0.75])))
+    kinds = rng.integers(0, 3, size=rng.integers(1, 4))
+    lights = []
+    for k in kinds:
+        p = (rng.random(3) - 0.5).astype(np.float32) * np.float32(1.0) + np.array([0, 0.4, 0], dtype=np.float32)
+        if k == 0:
+            lights.append(sio.point_light(tuple(p), tuple(rng.random(3).astype(np.float32))))
+        elif k == 1:
+            lights.append(sio.segment_light(tuple(p), tuple(p + np.float32(0.2)), (0.9, 0.2, 0.2), (0.2, 0.3, 0.9)))
+        else:
+            lights.append(sio.parallelogram_light(tuple(p), (0.2, 0, 0), (0, 0, 0.2), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)))
+    scn.lights = lights
+    b = lambda p=0.5: int(rng.random() < p)  # noqa: E731
+    spp = int(rng.choice([1, 1, 2, 4, 5, 9]))
+    f = common.features(
+        enableShading=b(0.85), enableReflections=b(), enableShadows=b(0.7), enableNormalInterp=b(), enableTextureMapping=b(),
+        enableAccelStructure=b(0.9), enableBilinearTextureFiltering=b(), enableTransparency=b(0.4), enableJitteredSampling=b(),
+        shadingModel=int(rng.integers(0, 4)), numPixelSamples=spp, numShadowSamples=int(rng.choice([0, 1, 2, 3], p=[0.08, 0.32, 0.3, 0.3])),
+        enableBvhSahBinning=b(0.3), enableBloomEffect=b(0.25), bloomFilterSize=int(rng.integers(3, 8)),
+        bloomThreshold=float(np.float32(rng.random() * 0.8)), enableDepthOfField=b(0.25),
+        depthOfFieldDistance=float(np.float32(1.5 + rng.random() * 2)), depthOfFieldCircleDiameter=float(np.float32(rng.random() * 0.2)),
+        numDepthOfFieldSamples=int(rng.integers(1, 4)), enableEnvironmentMap=int(env and b(0.8)), enableGlossyReflection=b(0.25),
+        numGlossySamples=int(rng.integers(1, 4)), glossyExponent=float(np.float32(rng.random())),
+        enableMotionBlur=b(0.25), motionBlurSamples=int(rng.integers(1, 3)), movement=float(np.float32(rng.random() * 1.5)),
+        maxRayDepth=int(rng.integers(0, 5)))
+    if name == "Spheres":
+        cam = sio.default_camera(1, 1, distance=float(3 + rng.random() * 3), look_at=(0, 0, 6), rotation_deg=(0, 180, 0))
+    else:
+        cam = sio.default_camera(1, 1, distance=float(1.8 + rng.random() * 3),
+                                 rotation_deg=(float(rng.integers(-40, 60)), float(rng.integers(-180, 180)), 0.0))
+    return name, scn, f, cam
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration_matches_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    name, scn, f, cam = _draw(rng)
+    w, h = int(rng.integers(17, 41)), int(rng.integers(17, 33))
+    cam["aspect"] = np.float32(w) / np.float32(h)
+    sah = bool(f["enableBvhSahBinning"])
+    nodes, prims, _, _ = orc.bvh_build(scn.primitives(), sah)
+    osc = orc.OracleScene(scn, nodes, prims)
+    motion = bool(f["enableMotionBlur"]) and not bool(f["enableDepthOfField"])
+    if motion:
+        want, so = osc.render_motion_blur(scn.primitives(), f, cam, w, h)
+    else:
+        want, so = osc.render(f, cam, w, h)
+    ctx = capi.Context(0, tree=int(rng.integers(0, 3)), tree_build=int(rng.integers(0, 2)))
+    try:
+        ctx.upload_scene(scn, sah_binning=sah)
+        assert ctx.nodes.tobytes() == nodes.tobytes()
+        ctx.set_features(f)
+        got, sg = ctx.render(cam, w, h)
+    finally:
+        ctx.close()
+    on = [k for k in f.dtype.names if k.startswith("enable") and f[k]]
+    print(f"seed {seed}: {name} {w}x{h} spp {int(f['numPixelSamples'])} depth {int(f['maxRayDepth'])} {' '.join(on)}: "
+          f"{sg['rays']} rays, {int(f['numShadowSamples'])} shadow samples, finite {float(np.isfinite(want).mean()):.3f}, "
+          f"bit-equal {float((got.view(np.uint32) == want.view(np.uint32)).mean()):.4f}")
+    assert sg["rays"] == so["rays"]
+    # (a light sampled zero times contributes 0 * (1 / 0), as the reference computes it: not a number, in both)
+    finite = np.isfinite(want)
+    assert np.array_equal(finite, np.isfinite(got))
+    assert common.image_error(np.where(finite, got, 0), np.where(finite, want, 0))[0] <= 2e-5
