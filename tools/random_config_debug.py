@@ -19,7 +19,7 @@ capi = importlib.import_module("ray-tracer_amd.capi")
 seed = int(sys.argv[1])
 rng = np.random.default_rng(1000 + seed)
 name, scn, f, cam = t._draw(rng)
-w, h = int(rng.integers(17, 41)), int(rng.integers(17, 33))
+w, h = int(rng.integers(*t.W_RANGE)), int(rng.integers(*t.H_RANGE))
 cam["aspect"] = np.float32(w) / np.float32(h)
 sah = bool(f["enableBvhSahBinning"])
 nodes, prims, _, _ = orc.bvh_build(scn.primitives(), sah)
