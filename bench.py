@@ -246,6 +246,8 @@ def main():
     ap.add_argument("--camera-distance", type=float, default=3.0,
                     help="the reference's default camera is at 3.0 (src/config.h:18-23); 1.6 fills the frame with the model")
     ap.add_argument("--in-flight", type=int, default=0, help="frames in flight (contexts/streams used round-robin)")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="rt_ctx_set_option on every context (A/B measurements), e.g. reference_boxes=0")
     ap.add_argument("--launch-check", action="store_true",
                     help="run the N-rank control flow (launcher, rendezvous, gather, reductions) on the CPU over gloo and leave")
     args = ap.parse_args()
@@ -293,7 +295,7 @@ def main():
     stride = capi.shard_floats(width, height, 0, world)
     ctxs, streams, frames, packeds, gathereds = [], [], [], [], []
     for _ in range(lanes):
-        c = capi.Context(local_rank)
+        c = capi.Context(local_rank, **{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.ctx_option})
         c.upload_scene(scene)
         c.set_features(features)
         ctxs.append(c)
@@ -441,7 +443,7 @@ def main():
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "rays_per_frame": int(rays_total),
-                       "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)", "frames_in_flight": lanes,
+                       "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)", "frames_in_flight": lanes, **({"ctx_options": args.ctx_option} if args.ctx_option else {}),
                        "scene_note": "dragon.obj is absent from the reference snapshot; procedural stand-in with the same triangle count"},
             "roofline": roof,
         }

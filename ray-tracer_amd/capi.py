@@ -103,7 +103,7 @@ def shard_floats(width, height, shard, n_shard) -> int:
     return int(lib().rt_shard_floats(width, height, shard, n_shard))
 
 
-OPTIONS = {"tree": 1, "per_pixel": 2, "strict_intersect": 3, "workspace_bytes": 4, "timing": 5, "tree_build": 6}  # enum rt_option
+OPTIONS = {"tree": 1, "per_pixel": 2, "strict_intersect": 3, "workspace_bytes": 4, "timing": 5, "tree_build": 6, "reference_boxes": 7}  # enum rt_option
 
 
 class Context:

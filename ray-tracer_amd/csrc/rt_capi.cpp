@@ -135,6 +135,20 @@ struct rt_ctx {
     // 2 = own SAH hierarchy over the caller's primitives, each a leaf of its own under its own box
     int treeMode = 2;
     bool treeBuildOnDevice = false; // RT_OPT_TREE_BUILD: the library's own hierarchy by the device's binned builder
+    bool referenceBoxes = true;     // RT_OPT_REFERENCE_BOXES: lose the hits the reference's box routine loses
+    // What a frame's geometry and the memory at hand say about its pixel batches, kept from the last render call:
+    // a renderer asked for the same frame again (a still camera, a benchmark) has nothing to work out per tile.
+    struct Batch {
+        uint32_t firstTile, tiles;
+        uint64_t cand;
+    };
+    struct FramePlan {
+        std::vector<uint8_t> tilesKey, planKey; // the inputs the two parts below were made from
+        std::vector<uint16_t> tileCand;         // per tile of the shard: pixels that can see the scene's box
+        std::vector<uint32_t> validBefore;      // per tile: real (non-padding) pixels of the tiles before it; one more entry at the end
+        std::vector<Batch> batches;
+        uint64_t maxTiles = 0, maxCand = 0;
+    } plan;
     size_t workspaceCap = 64ull << 30; // bytes the wavefront path may hold
     // working memory of the queue-based path (one allocation, grow-only)
     void* wsBase = nullptr;
@@ -353,6 +367,10 @@ try {
         return RT_OK;
     case RT_OPT_TREE_BUILD:
         ctx->treeBuildOnDevice = value != 0;
+        return RT_OK;
+    case RT_OPT_REFERENCE_BOXES:
+        ctx->referenceBoxes = value != 0;
+        ctx->scene.leafBoxes = ctx->referenceBoxes ? ctx->dLeafBoxes : nullptr;
         return RT_OK;
     default:
         return fail(ctx, RT_ERR_INVALID, "rt_ctx_set_option: unknown option %d", option);
@@ -1053,7 +1071,7 @@ try {
     s.nPrims = n_prims;
     s.tieByIndex = (ownTree && ctx->treeMode == 2) ? 1 : 0;
     s.refNodes = replayable ? ctx->dRefNodes : nullptr;
-    s.leafBoxes = ctx->dLeafBoxes;
+    s.leafBoxes = ctx->referenceBoxes ? ctx->dLeafBoxes : nullptr;
     s.strictIntersect = ctx->strictIntersect ? 1 : 0;
     s.nMeshes = static_cast<int32_t>(n_meshes);
     s.nSpheres = static_cast<int32_t>(n_spheres);
@@ -1299,10 +1317,12 @@ static int traceKnobs(int minActive, int a, int b)
 // only they need room in the pools of hits and light samples.  Every real pixel counts when the bound
 // does not apply: a corner beside or behind the camera, rays that start on a lens instead of the camera's
 // position (depth of field), spheres in the scene or the acceleration structure off (every ray is traced).
-static std::vector<uint16_t> candidatePixelsPerTile(const rt_ctx* ctx, const rt_camera& camera, const DevFrame& fr, int width, int height)
+static void candidatePixelsPerTile(const rt_ctx* ctx, const rt_camera& camera, const DevFrame& fr, int width, int height,
+    std::vector<uint16_t>& out, std::vector<uint32_t>& validBefore)
 {
     const uint32_t nTiles = fr.nWork / 64u;
-    std::vector<uint16_t> out(nTiles);
+    out.assign(nTiles, 0);
+    validBefore.assign(nTiles + 1, 0u);
     const rt_features& F = ctx->features;
     const DevScene& sc = ctx->scene;
     bool bounded = F.enableAccelStructure && !F.enableDepthOfField && sc.nSpheres == 0 && sc.nPrims != 0;
@@ -1329,14 +1349,30 @@ static std::vector<uint16_t> candidatePixelsPerTile(const rt_ctx* ctx, const rt_
             y0 = static_cast<int>(std::max(0.0, std::floor(loy) - 1.0)), y1 = static_cast<int>(std::min(double(height - 1), std::floor(hiy) + 1.0));
         }
     }
+    // tile t of the shard is tile t * nShard + shard of the frame: column and row kept by stepping, not by division
+    int col = fr.shard % fr.tilesX, row = fr.shard / fr.tilesX;
+    const int colStep = fr.nShard % fr.tilesX, rowStep = fr.nShard / fr.tilesX;
+    uint32_t valid = 0;
     for (uint32_t t = 0; t < nTiles; t++) {
-        const uint64_t tile = static_cast<uint64_t>(t) * fr.nShard + fr.shard;
-        const int tx = static_cast<int>(tile % fr.tilesX) * kTile, ty = static_cast<int>(tile / fr.tilesX) * kTile;
+        const int tx = col * kTile, ty = row * kTile;
         const int ax = std::max(tx, x0), bx = std::min(std::min(tx + kTile, width) - 1, x1);
         const int ay = std::max(ty, y0), by = std::min(std::min(ty + kTile, height) - 1, y1);
         out[t] = (bx >= ax && by >= ay) ? static_cast<uint16_t>((bx - ax + 1) * (by - ay + 1)) : 0;
+        validBefore[t] = valid;
+        valid += static_cast<uint32_t>(std::min(kTile, width - tx) * std::min(kTile, height - ty));
+        col += colStep, row += rowStep;
+        if (col >= fr.tilesX)
+            col -= fr.tilesX, row++;
     }
-    return out;
+    validBefore[nTiles] = valid;
+}
+
+// bytes of plain values, appended: the keys of rt_ctx::FramePlan
+template <typename T>
+static void keyAdd(std::vector<uint8_t>& key, const T& v)
+{
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(&v);
+    key.insert(key.end(), p, p + sizeof(T));
 }
 
 // `arena`: null = working buffers are the context's own (allocated and grown as needed); else they
@@ -1531,20 +1567,35 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
 
         // Which pixels can have a camera ray that enters the scene's box at all: only those make hits, and the
         // pools of hits and light samples -- nine tenths of the working memory -- are sized for them alone.
-        const std::vector<uint16_t> tileCand = candidatePixelsPerTile(ctx, *camera, fr, width, height);
+        rt_ctx::FramePlan& fp = ctx->plan;
+        {
+            std::vector<uint8_t> key;
+            keyAdd(key, *camera), keyAdd(key, width), keyAdd(key, height), keyAdd(key, shard), keyAdd(key, nShard);
+            keyAdd(key, ctx->generation), keyAdd(key, F.enableAccelStructure), keyAdd(key, F.enableDepthOfField);
+            if (key != fp.tilesKey) {
+                candidatePixelsPerTile(ctx, *camera, fr, width, height, fp.tileCand, fp.validBefore);
+                fp.tilesKey.swap(key);
+                fp.planKey.clear();
+            }
+        }
+        const std::vector<uint16_t>& tileCand = fp.tileCand;
         const uint32_t nTiles = fr.nWork / 64u;
         // per pixel slot: head, count, prefix (and environment colour) of each of its camera rays; per candidate
         // pixel: its queued camera rays and the worst case of its hits with their light samples
         const uint64_t perSlot = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + (F.enableEnvironmentMap ? 12 : 0));
         const uint64_t perCand = static_cast<uint64_t>(wp.R) * 32 + nodesPerPixel * perNodeBytes;
-        struct Batch {
-            uint32_t firstTile, tiles;
-            uint64_t cand;
-        };
-        std::vector<Batch> batches;
-        uint64_t maxTiles = 0, maxCand = 0;
+        typedef rt_ctx::Batch Batch;
+        std::vector<Batch>& batches = fp.batches;
+        uint64_t& maxTiles = fp.maxTiles;
+        uint64_t& maxCand = fp.maxCand;
         // consecutive tiles, as many as the cap lets in; false when one tile alone exceeds it
         auto plan = [&](uint64_t cap, uint64_t fixed) {
+            std::vector<uint8_t> key;
+            keyAdd(key, cap), keyAdd(key, fixed), keyAdd(key, perSlot), keyAdd(key, perCand), keyAdd(key, wp.R), keyAdd(key, nodesPerPixel);
+            keyAdd(key, nodeSlack), keyAdd(key, nodeCap);
+            if (key == fp.planKey && !batches.empty())
+                return true; // the same frame under the same limits as last time
+            fp.planKey.clear();
             batches.clear();
             maxTiles = maxCand = 0;
             const uint64_t room = cap > fixed ? cap - fixed : 0;
@@ -1566,6 +1617,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             }
             if (cur.tiles)
                 batches.push_back(cur);
+            fp.planKey.swap(key);
             return true;
         };
         size_t want[10];
@@ -1651,12 +1703,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                 HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(dCounters) + offsetof(DevCounters, next), 0,
                     offsetof(DevCounters, loopIters) - offsetof(DevCounters, next), stream));
             // real pixels of the batch's tiles (edge tiles are padded to 8x8 slots)
-            uint64_t validPixels = 0;
-            for (uint64_t t = bt.firstTile; t < static_cast<uint64_t>(bt.firstTile) + bt.tiles; t++) {
-                const uint64_t tile = t * static_cast<uint64_t>(nShard) + shard;
-                const int tx = static_cast<int>(tile % fr.tilesX), ty = static_cast<int>(tile / fr.tilesX);
-                validPixels += static_cast<uint64_t>(std::min(kTile, width - tx * kTile)) * std::min(kTile, height - ty * kTile);
-            }
+            const uint64_t validPixels = fp.validBefore[bt.firstTile + bt.tiles] - fp.validBefore[bt.firstTile];
             wp.validPaths = static_cast<uint32_t>(validPixels * wp.R);
             const int pathBlocks = pathBlocksAll;
             const int shadowBlocks = ctx->numCU * shadowPerCU;

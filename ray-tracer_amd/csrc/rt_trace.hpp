@@ -473,7 +473,7 @@ struct Tracer {
 
     __device__ __forceinline__ void settleTie(RayState& r) const
     {
-        if (accel && sc.refNodes != nullptr && r.hitPrim >= 0 && !r.tie && !surelyReached(r))
+        if (accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr && r.hitPrim >= 0 && !r.tie && !surelyReached(r))
             r.tie = true;
         if (__builtin_expect(r.tie, 0) && sc.refNodes != nullptr && accel) {
             const uint2 res = replayReference(sc.refNodes, sc.tris, stk, stride, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.slen,

@@ -707,7 +707,8 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR RT_SHADOW_TRANSP_ATTR
                 }
             }
         }
-        if (TRANSP && have && !r.active && !r.tie && r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && !tracer.surelyReached(r))
+        if (TRANSP && have && !r.active && !r.tie && r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr
+            && !tracer.surelyReached(r))
             r.tie = true; // the reference's own boxes may have kept it from this hit: same way out as a tie
         if (TRANSP && have && !r.active && r.tie) {
                 // Two materials met at exactly the same distance: which of them the reference keeps takes
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR RT_SHADOW_TRANSP_ATTR
                     // An occluder the reference's own box tests may have kept it from (Tracer::surelyReached) proves
                     // nothing: the sample goes on a list and shadowRedoKernel follows it the reference's way.
                     // (A visible sample needs no such care: what the reference finds is among what was found here.)
-                    if (r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && !tracer.surelyReached(r)) {
+                    if (r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr && !tracer.surelyReached(r)) {
                         wb.redo[atomicAdd(&ctr->redo.v, 1u)] = item;
                     } else {
                         float* dst = wb.contrib + 3u * (size_t)item;
@@ -1142,7 +1143,7 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, in
         (void)hipEventRecord(marks[2], stream);
     if (transp) // (otherwise the samples were shaded when they were generated)
         hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
-    else if (ft.shadows && ft.accel && sc.refNodes != nullptr)
+    else if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr)
         hipLaunchKernelGGL(shadowRedoKernel, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr);
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
     const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
