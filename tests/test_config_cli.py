@@ -76,7 +76,7 @@ def test_command_line_rendering_writes_the_oracles_bitmaps(tmp_path):
     sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
     import orc
     cli = importlib.import_module("ray-tracer_amd.cli")
-    for name in ("cornell_two_cameras.toml", "teapot_file_scene.toml"):
+    for name in ("cornell_two_cameras.toml", "teapot_file_scene.toml", "cornell_motion_blur.toml"):
         cfg = cfgmod.read_config_file(os.path.join(CONFIGS, name), common.DATA)
         cfg.outputDir = str(tmp_path / name)
         done = cli.render_config(cfg, 0, start_time="T")
@@ -86,7 +86,11 @@ def test_command_line_rendering_writes_the_oracles_bitmaps(tmp_path):
         w, h = cfg.windowSize
         for i, (path, frame, stats) in enumerate(done):
             assert os.path.basename(path) == f"{scene_name}_T_cam_{i}.bmp"
-            ref, st_o = osc.render(cfg.features, cfg.cameras[i].trackball(w, h), w, h)
+            if cfg.features["enableMotionBlur"] and not cfg.features["enableDepthOfField"]:  # src/render.cpp:22-25
+                ref, st_o = osc.render_motion_blur(scene.primitives(), cfg.features, cfg.cameras[i].trackball(w, h), w, h)
+                assert ref.any()
+            else:
+                ref, st_o = osc.render(cfg.features, cfg.cameras[i].trackball(w, h), w, h)
             assert stats["rays"] == st_o["rays"]
             assert common.image_error(frame, ref)[0] <= 2e-5
             got = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
