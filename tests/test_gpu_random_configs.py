@@ -127,7 +127,12 @@ def test_random_configuration_matches_oracle(seed):
         want, so = osc.render_motion_blur(scn.primitives(), f, cam, w, h)
     else:
         want, so = osc.render(f, cam, w, h)
-    ctx = capi.Context(0, tree=int(rng.integers(0, 3)), tree_build=int(rng.integers(0, 2)))
+    options = dict(tree=int(rng.integers(0, 3)), tree_build=int(rng.integers(0, 2)))
+    if rng.random() < 0.3:  # a workspace so small that the frame is rendered in several pixel batches
+        options["workspace_bytes"] = int(rng.choice([2 << 20, 8 << 20, 32 << 20]))
+    if rng.random() < 0.2:
+        options["per_pixel"] = 1
+    ctx = capi.Context(0, **options)
     try:
         ctx.upload_scene(scn, sah_binning=sah)
         assert ctx.nodes.tobytes() == nodes.tobytes()
