@@ -448,10 +448,11 @@ struct Tracer {
     // lies on the right side of the hit's own distance.  The rest (a hit at a vertex that is a corner of the
     // box; a triangle that lies IN a face of the box, as in axis-aligned scenes) gets the routine itself on that
     // one box, and a ray it turns away there is settled by the replay.
-    __device__ __forceinline__ bool surelyReached(const RayState& r) const
+    // (the first, quick part on its own: the hit's point inside the box of the caller's leaf by a margin)
+    __device__ __forceinline__ bool insideLeafBox(const RayState& r, f3& lo, f3& hi) const
     {
         const float4 b0 = sc.leafBoxes[2u * (uint32_t)r.hitPrim], b1 = sc.leafBoxes[2u * (uint32_t)r.hitPrim + 1u];
-        f3 lo = { b0.x, b0.y, b0.z }, hi = { b0.w, b1.x, b1.y };
+        lo = { b0.x, b0.y, b0.z }, hi = { b0.w, b1.x, b1.y };
         if (MOTION) {
             lo = moved(r.mv, lo);
             hi = moved(r.mv, hi);
@@ -463,7 +464,13 @@ struct Tracer {
         const float my = (fabsf(r.o.y) + fabsf(td.y) + fabsf(lo.y) + fabsf(hi.y)) * k;
         const float mz = (fabsf(r.o.z) + fabsf(td.z) + fabsf(lo.z) + fabsf(hi.z)) * k;
         // (written so that a value that is not a number anywhere answers "not sure")
-        if (lo.x + mx < X.x && X.x < hi.x - mx && lo.y + my < X.y && X.y < hi.y - my && lo.z + mz < X.z && X.z < hi.z - mz)
+        return lo.x + mx < X.x && X.x < hi.x - mx && lo.y + my < X.y && X.y < hi.y - my && lo.z + mz < X.z && X.z < hi.z - mz;
+    }
+
+    __device__ __forceinline__ bool surelyReached(const RayState& r) const
+    {
+        f3 lo, hi;
+        if (insideLeafBox(r, lo, hi))
             return true;
         const float l3[3] = { lo.x, lo.y, lo.z }, h3[3] = { hi.x, hi.y, hi.z };
         const float o3[3] = { r.o.x, r.o.y, r.o.z }, d3[3] = { r.d.x, r.d.y, r.d.z };
