@@ -662,7 +662,10 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
 #endif
 // (the variant that follows light through transparent surfaces needs a register or two more than six
 // waves per SIMD leave it; held to that budget it keeps them, at the price of a spill outside the loop)
-#define RT_SHADOW_TRANSP_ATTR(on) __attribute__((amdgpu_waves_per_eu((on) ? 6 : 1)))
+#ifndef RT_TRANSP_WAVES
+#define RT_TRANSP_WAVES 6
+#endif
+#define RT_SHADOW_TRANSP_ATTR(on) __attribute__((amdgpu_waves_per_eu((on) ? RT_TRANSP_WAVES : 1)))
 template <bool STATS, bool TRANSP>
 __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR RT_SHADOW_TRANSP_ATTR(TRANSP && !STATS) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
