@@ -132,14 +132,22 @@ def test_random_configuration_matches_oracle(seed):
         options["workspace_bytes"] = int(rng.choice([2 << 20, 8 << 20, 32 << 20]))
     if rng.random() < 0.2:
         options["per_pixel"] = 1
-    ctx = capi.Context(0, **options)
-    try:
-        ctx.upload_scene(scn, sah_binning=sah)
-        assert ctx.nodes.tobytes() == nodes.tobytes()
-        ctx.set_features(f)
-        got, sg = ctx.render(cam, w, h)
-    finally:
-        ctx.close()
+    for attempt in (0, 1):
+        ctx = capi.Context(0, **options)
+        try:
+            ctx.upload_scene(scn, sah_binning=sah)
+            assert ctx.nodes.tobytes() == nodes.tobytes()
+            ctx.set_features(f)
+            got, sg = ctx.render(cam, w, h)
+            break
+        except capi.RtError as e:
+            # the drawn cap can be smaller than what one 8x8 tile of a heavy feature set needs: refused, as documented
+            if attempt == 0 and e.code == -2 and "workspace_bytes" in options:
+                del options["workspace_bytes"]
+                continue
+            raise
+        finally:
+            ctx.close()
     on = [k for k in f.dtype.names if k.startswith("enable") and f[k]]
     print(f"seed {seed}: {name} {w}x{h} spp {int(f['numPixelSamples'])} depth {int(f['maxRayDepth'])} {' '.join(on)}: "
           f"{sg['rays']} rays, {int(f['numShadowSamples'])} shadow samples, finite {float(np.isfinite(want).mean()):.3f}, "
