@@ -146,6 +146,7 @@ struct rt_ctx {
         std::vector<uint8_t> tilesKey, planKey; // the inputs the two parts below were made from
         std::vector<uint16_t> tileCand;         // per tile of the shard: pixels that can see the scene's box
         std::vector<uint32_t> validBefore;      // per tile: real (non-padding) pixels of the tiles before it; one more entry at the end
+        int rect[4] = { 0, 0, 0, 0 };           // x0, x1, y0, y1 (inclusive): the pixels that can see the scene's box
         std::vector<Batch> batches;
         uint64_t maxTiles = 0, maxCand = 0;
     } plan;
@@ -1318,7 +1319,7 @@ static int traceKnobs(int minActive, int a, int b)
 // does not apply: a corner beside or behind the camera, rays that start on a lens instead of the camera's
 // position (depth of field), spheres in the scene or the acceleration structure off (every ray is traced).
 static void candidatePixelsPerTile(const rt_ctx* ctx, const rt_camera& camera, const DevFrame& fr, int width, int height,
-    std::vector<uint16_t>& out, std::vector<uint32_t>& validBefore)
+    std::vector<uint16_t>& out, std::vector<uint32_t>& validBefore, int rect[4])
 {
     const uint32_t nTiles = fr.nWork / 64u;
     out.assign(nTiles, 0);
@@ -1349,6 +1350,7 @@ static void candidatePixelsPerTile(const rt_ctx* ctx, const rt_camera& camera, c
             y0 = static_cast<int>(std::max(0.0, std::floor(loy) - 1.0)), y1 = static_cast<int>(std::min(double(height - 1), std::floor(hiy) + 1.0));
         }
     }
+    rect[0] = x0, rect[1] = x1, rect[2] = y0, rect[3] = y1;
     // tile t of the shard is tile t * nShard + shard of the frame: column and row kept by stepping, not by division
     int col = fr.shard % fr.tilesX, row = fr.shard / fr.tilesX;
     const int colStep = fr.nShard % fr.tilesX, rowStep = fr.nShard / fr.tilesX;
@@ -1402,6 +1404,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     fr.shard = shard, fr.nShard = nShard;
     fr.nWork = static_cast<uint32_t>(shardTiles(width, height, shard, nShard) * 64);
     fr.packed = (nShard == 1) ? 0 : 1;
+    fr.candX0 = 0, fr.candX1 = width - 1, fr.candY0 = 0, fr.candY1 = height - 1;
 
     const int blockThreads = kBlockThreads;
     const int maxPerCU = 32 / kBlockWaves; // a compute unit holds 32 wavefronts
@@ -1573,11 +1576,12 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             keyAdd(key, *camera), keyAdd(key, width), keyAdd(key, height), keyAdd(key, shard), keyAdd(key, nShard);
             keyAdd(key, ctx->generation), keyAdd(key, F.enableAccelStructure), keyAdd(key, F.enableDepthOfField);
             if (key != fp.tilesKey) {
-                candidatePixelsPerTile(ctx, *camera, fr, width, height, fp.tileCand, fp.validBefore);
+                candidatePixelsPerTile(ctx, *camera, fr, width, height, fp.tileCand, fp.validBefore, fp.rect);
                 fp.tilesKey.swap(key);
                 fp.planKey.clear();
             }
         }
+        fr.candX0 = fp.rect[0], fr.candX1 = fp.rect[1], fr.candY0 = fp.rect[2], fr.candY1 = fp.rect[3];
         const std::vector<uint16_t>& tileCand = fp.tileCand;
         const uint32_t nTiles = fr.nWork / 64u;
         // per pixel slot: head, count, prefix (and environment colour) of each of its camera rays; per candidate

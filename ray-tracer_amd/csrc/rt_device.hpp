@@ -180,6 +180,9 @@ struct DevFrame {
     int32_t shard, nShard;
     uint32_t nWork; // local pixels = local tiles * 64
     int32_t packed; // 0: write Screen order, 1: write shard-packed tiles
+    // The pixels (inclusive rectangle) outside of which no camera ray can enter the scene's box: the whole frame
+    // where no such bound holds (queue-based renderer; filled in by the host with the frame's batch plan).
+    int32_t candX0, candX1, candY0, candY1;
 };
 
 // Threads per block of every kernel that traverses (their LDS stacks are laid out for it).

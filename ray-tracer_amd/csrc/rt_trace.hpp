@@ -640,6 +640,12 @@ __device__ __forceinline__ void cameraRay(const DevCamera& cam, const DevFeat& f
     }
 }
 
+// Can a camera ray of this pixel enter the scene's box at all (DevFrame::cand*)?
+__device__ __forceinline__ bool seesScene(const DevFrame& fr, int px, int py)
+{
+    return px >= fr.candX0 && px <= fr.candX1 && py >= fr.candY0 && py <= fr.candY1;
+}
+
 // Pixel of local work slot `slot` (64 consecutive slots = one 8x8 tile; tile k
 // of the frame belongs to shard k % nShard).  Returns false for the padding
 // pixels of partial edge tiles.

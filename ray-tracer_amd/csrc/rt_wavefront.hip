@@ -174,6 +174,11 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
             const uint32_t slot = wp.slotBegin + pixel, i = path - pixel * wp.R;
             int px, py;
             if (slotToPixel(fr, slot, px, py)) { // padding pixels of partial edge tiles have no rays
+                // A pixel from which the scene's box cannot be seen: every ray of it misses, and unless the
+                // background has a colour of its own there is nothing to work out for it.
+                // (combineKernel knows the same rectangle and writes such a pixel's black without reading anything)
+                if (!ft.envMap && !seesScene(fr, px, py)) {
+                } else {
                 const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
                 const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
                 const uint32_t sample = (DOF && ft.dof) ? fastDiv(i, ft.divDof) : i; // i / dofN
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
                         wb.pathEnv[3u * path + 1] = env.y;
                         wb.pathEnv[3u * path + 2] = env.z;
                     }
+                }
                 }
             }
         }
@@ -494,7 +500,7 @@ __global__ void prefixKernel(const DevFrame fr, const WfParams wp, const WfBuffe
     if (s >= wp.nSlots)
         return;
     int px, py;
-    if (!slotToPixel(fr, wp.slotBegin + s, px, py))
+    if (!slotToPixel(fr, wp.slotBegin + s, px, py) || !seesScene(fr, px, py)) // (no hits, no bases to count)
         return;
     uint32_t base = 0;
     if ((wp.R & 3u) == 0u) { // four paths at a time: one 4-B load of counts, one 16-B store of bases
@@ -1058,11 +1064,14 @@ __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const De
     const uint32_t s = blockIdx.x * pixelsPerBlock + pl;
     int px = 0, py = 0;
     const bool valid = pl < pixelsPerBlock && s < wp.nSlots && slotToPixel(fr, wp.slotBegin + s, px, py);
+    // a pixel that cannot see the scene's box: every ray of it missed; black unless the background has a colour of
+    // its own (the camera kernel wrote nothing for it)
+    const bool sees = valid && (ft.envMap || seesScene(fr, px, py));
     f3 L = mk3(0.0f);
     for (uint32_t base = 0; base < wp.R; base += perRound) {
         const uint32_t i = base + j;
         f3 v = mk3(0.0f);
-        if (valid && i < wp.R)
+        if (sees && i < wp.R)
             v = TRANSP ? pathValueTree(sc, ft, wp, wb, s * wp.R + i) : pathValue(sc, ft, wp, wb, s * wp.R + i);
         vals[3u * threadIdx.x + 0] = v.x;
         vals[3u * threadIdx.x + 1] = v.y;
