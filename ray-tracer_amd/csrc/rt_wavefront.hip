@@ -1147,10 +1147,13 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, in
         (void)hipEventRecord(marks[0], stream);
     const int pb = (int)((wp.nSlots + 255) / 256);
     hipLaunchKernelGGL(prefixKernel, dim3(pb), dim3(256), 0, stream, fr, wp, wb);
-    // (six blocks of this kernel fit a compute unit, and a grid of eight ran a full round and then a third of one:
-    // 0.70 ms for the headline frame's samples against 0.57 with 6, 12 or 24 blocks per unit)
+    // Six blocks of this kernel fit a compute unit, so a grid of eight per unit runs a full round and then a third of
+    // one: 0.70 ms for the headline frame's samples alone, against 0.57 with 6, 12 or 24 per unit.  With several
+    // frames in flight that last third is where the other frames' traversal waves get in, and the order reverses:
+    // 5.56-5.59 ms a frame with 8, 5.61 with 6, 5.65-5.66 with 12 (three frames in flight, one box, two rounds of
+    // each).  The default serves frames in flight; build with -DRT_GEN_BLOCKS=12 for one frame at a time.
 #ifndef RT_GEN_BLOCKS
-#define RT_GEN_BLOCKS 12
+#define RT_GEN_BLOCKS 8
 #endif
     hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * RT_GEN_BLOCKS), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr, sc.lights);
     if (marks)
