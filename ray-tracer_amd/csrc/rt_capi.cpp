@@ -1027,6 +1027,18 @@ try {
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
+    // On the device an inner child reference is the BYTE offset of the child's record (index * 32), so that a
+    // traversal step forms no address: the loads take it as their 32-bit offset from the array's base.
+    if (pairs.size() / 2 > (size_t(1) << 26))
+        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: %zu sibling-pair records exceed the %u supported", pairs.size() / 2, 1u << 26);
+    for (size_t k = 1; k < pairs.size(); k += 2) {
+        if ((pairs[k].z & kLeafFlag) == 0)
+            pairs[k].z *= kPairBytes;
+        if ((pairs[k].w & kLeafFlag) == 0)
+            pairs[k].w *= kPairBytes;
+    }
+    if ((rootRef & kLeafFlag) == 0)
+        rootRef *= kPairBytes;
     HIP_TRY(ctx, uploadVec(&ctx->dPairs, pairs));
     ctx->numPairs = static_cast<uint32_t>(pairs.size() / 2);
     // The caller's nodes, verbatim: a ray that meets two primitives at exactly the same distance is

@@ -79,7 +79,8 @@ RT_HD f3 quatRotate(float qw, f3 q, f3 v)
 //         rounded up, so a quantised box always contains the float box; the
 //         traversal only has to be conservative, the triangle test decides.
 //           [0] Lx Ly Lz Rx   [1] Ry Rz refL refR     each box dword = lo | hi << 16
-//         child ref: inner -> index of the child's own pair record;
+//         child ref: inner -> byte offset of the child's own pair record (index * 32: a step's
+//                             two loads take it as their offset from the array's base);
 //                    leaf  -> kLeafFlag | count << 27 | offset   (count <= 15)
 // tris  : one 96-B record per primitive (6 x dwordx4), holding the
 //         ray-independent part of the reference's plane + three edge tests:
@@ -94,6 +95,7 @@ RT_HD f3 quatRotate(float qw, f3 q, f3 v)
 //           [3] uv1.y uv2.xy meshID(bits)
 // ----------------------------------------------------------------------------
 constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kPairBytes = 32u;
 constexpr uint32_t kRefNone = 0x7fffffffu; // "no node": traversal finished
 constexpr uint32_t kLeafOffsetMask = (1u << 27) - 1u;
 constexpr int kMaxLeafCount = 15;

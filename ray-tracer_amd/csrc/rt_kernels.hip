@@ -458,6 +458,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void renderKernel(cons
     L.r.cur = kRefNone;
     L.r.pend = 0u;
     L.r.top = tracer.stk;
+    L.r.tos = kRefNone;
     L.r.active = false;
     L.depth = 0;
 
@@ -563,6 +564,7 @@ __global__ __launch_bounds__(kBlockThreads) void intersectKernel(const DevScene 
     L.cur = kRefNone;
     L.pend = 0u;
     L.top = tracer.stk;
+    L.tos = kRefNone;
     L.active = false;
     L.nInner = L.nTris = 0;
     if (i < n) {

@@ -11,6 +11,16 @@
 #define RT_INNER_STEPS 4 // sibling pairs a lane may visit between two votes of the traversal loop
 #endif
 
+#ifndef RT_STACK_TOS
+#define RT_STACK_TOS 0 // the top entry of a lane's traversal stack lives in a register (see Tracer::pop)
+#endif
+#ifndef RT_ROLLED_STEPS
+#define RT_ROLLED_STEPS 0 // the inner steps between two votes as a loop instead of unrolled code
+#endif
+#ifndef RT_PARK_IN_BLOCK
+#define RT_PARK_IN_BLOCK 0 // a lane that reaches a leaf between two votes parks it there and then
+#endif
+
 namespace rt {
 
 enum RayKind : int { K_RADIANCE = 0, K_SHADOW_ANY = 1, K_SHADOW_CLOSEST = 2 };
@@ -39,6 +49,7 @@ struct RayState {
     uint32_t pend;    // parked leaf reference whose primitives are still to be tested, 0 = none
     uint32_t li, le;  // next primitive of the parked leaf and its end, as indices into the float4 array (6 per primitive)
     LdsWords top;     // first free entry of this lane's traversal stack
+    uint32_t tos;     // the stack's top entry (RT_STACK_TOS): what the next pop returns
     bool active;      // still inside the traversal loop
     bool tie;         // two primitives were met at exactly the same distance: see Tracer::settleTie
     uint32_t nInner, nTris;
@@ -135,15 +146,31 @@ struct Tracer {
 
     // The bottom entry of every stack holds kRefNone (begin()), so a pop needs no
     // emptiness check: the last pop of a traversal returns "no node".
+    // With RT_STACK_TOS the top entry is held in a register: a pop hands it out at once and the LDS read
+    // that fetches the entry below is only waited for at the lane's next stack operation, a box test or
+    // more later, instead of in the middle of the step (every step of a wave has some lane popping).
     __device__ __forceinline__ uint32_t pop(RayState& r) const
     {
+#if RT_STACK_TOS
+        const uint32_t ref = r.tos;
+        r.top -= stride;
+        r.tos = *r.top;
+        return ref;
+#else
         r.top -= stride;
         return *r.top;
+#endif
     }
     __device__ __forceinline__ void push(RayState& r, uint32_t ref) const
     {
+#if RT_STACK_TOS
+        *r.top = r.tos;
+        r.top += stride;
+        r.tos = ref;
+#else
         *r.top = ref;
         r.top += stride;
+#endif
     }
 
     __device__ __forceinline__ void begin(RayState& r, f3 o, f3 d, float tmax, int kind) const
@@ -154,8 +181,14 @@ struct Tracer {
         r.slen = tmax;
         r.kind = kind;
         r.hitPrim = kHitNone;
+#if RT_STACK_TOS
+        *stk = kRefNone; // in memory below the register-held top, so that the pop of the last entry reads "no node" again
+        r.top = stk + stride;
+        r.tos = kRefNone;
+#else
         r.top = stk;
         push(r, kRefNone);
+#endif
         r.cur = kRefNone;
         r.pend = 0u;
         r.active = false;
@@ -272,10 +305,15 @@ struct Tracer {
         const float fy = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(wy, K, r.selFy)), r.A.y, r.Bf.y);
         const float nz = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(wz, K, r.selNz)), r.A.z, r.Bn.z);
         const float fz = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(wz, K, r.selFz)), r.A.z, r.Bf.z);
-        const float tIn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+        // The ray meets the box between max(tIn, 0) and min(tOut, ray.t): tIn <= tOut, tIn <= ray.t and
+        // 0 <= tOut, asked as one sign (the sign of a difference of two floats is that of their comparison).
+        // Comparisons, minima and permutes issue at half the rate of additions and multiply-adds on gfx950
+        // (tools/valu_probe.hip), so two subtractions and a three-way minimum are cheaper than two compares
+        // and a clamp.  `entry` only orders the two children; it may be negative (origin inside the box).
+        const float tIn = fmaxf(fmaxf(nx, ny), nz);
         const float tOut = fminf(fminf(fx, fy), fz);
         entry = tIn;
-        return tIn <= tOut && tIn <= r.tmax;
+        return fminf(fminf(tOut - tIn, r.tmax - tIn), tOut) >= 0.0f;
     }
 
     // Make `ref` the node to visit next.
@@ -330,10 +368,18 @@ struct Tracer {
             if (!leafMode) {
                 if (canInner)
                     innerStep(r);
+#if RT_ROLLED_STEPS
+#pragma unroll 1
+#else
 #pragma unroll
-                for (int k = 1; k < RT_INNER_STEPS; k++)
+#endif
+                for (int k = 1; k < RT_INNER_STEPS; k++) {
+#if RT_PARK_IN_BLOCK
+                    park(r);
+#endif
                     if (r.cur < kRefNone)
                         innerStep(r);
+                }
                 if (STATS) {
                     r.itInner++;
                     r.cycInner += (unsigned long long)(clock64() - t0);
@@ -367,12 +413,44 @@ struct Tracer {
     // One sibling-pair record (32 B): test both children, descend into the nearer.
     __device__ __forceinline__ void innerStep(RayState& r) const
     {
-        const uint4* p = sc.pairs + 2u * r.cur;
+        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.pairs) + r.cur);
         const uint4 w0 = p[0], w1 = p[1];
         if (STATS) {
             r.nInner++;
-            r.topHits[0] += r.cur < 1024u, r.topHits[1] += r.cur < 2048u, r.topHits[2] += r.cur < 4096u;
+            r.topHits[0] += r.cur < 1024u * kPairBytes, r.topHits[1] += r.cur < 2048u * kPairBytes, r.topHits[2] += r.cur < 4096u * kPairBytes;
         }
+#ifdef RT_PROBE_EXTRA_LOADS // sensitivity probes (tools/sensitivity.sh): work added to every step, results unused
+        {
+            uint4 x;
+            for (int k = 0; k < RT_PROBE_EXTRA_LOADS; k++)
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:32\n s_waitcnt vmcnt(0)" : "=v"(x) : "v"(r.cur), "s"(sc.pairs) : "memory");
+        }
+#endif
+#ifdef RT_PROBE_EXTRA_VALU
+        {
+            float x = r.tmax;
+            for (int k = 0; k < RT_PROBE_EXTRA_VALU; k++)
+                asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(r.A.x));
+        }
+#endif
+#ifdef RT_PROBE_EXTRA_VALU_B
+        {
+            float x = r.tmax;
+            for (int k = 0; k < RT_PROBE_EXTRA_VALU_B; k++)
+                asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(x) : "v"(r.A.x));
+        }
+#endif
+#ifdef RT_PROBE_EXTRA_SALU
+        for (int k = 0; k < RT_PROBE_EXTRA_SALU; k++)
+            asm volatile("s_add_u32 s100, s100, 1" ::: "s100");
+#endif
+#ifdef RT_PROBE_EXTRA_LDS
+        {
+            uint32_t x;
+            for (int k = 0; k < RT_PROBE_EXTRA_LDS; k++)
+                asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(x) : "v"((uint32_t)(size_t)stk) : "memory");
+        }
+#endif
         float eL, eR;
         const bool hL = qboxTest(w0.x, w0.y, w0.z, r, eL);
         const bool hR = qboxTest(w0.w, w1.x, w1.y, r, eR);

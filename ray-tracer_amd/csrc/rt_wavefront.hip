@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
                 uint32_t sLens = (DOF && ft.dof) ? lcgSkip(seed, wp.pixDraws + 2u * i) : seed;
                 f3 pof = { 0.0f, 0.0f, 0.0f };
                 cameraRay<DOF>(cam, ft, fr, px, py, sample * dofN, sPix, sLens, pof, o[j], d[j]);
-                enters[j] = ft.accel && tracer.entersScene(o[j], rcp3(d[j]));
+                // (the root test is widened against rounding; the host sized the ray queue and the hit pools by the pixels
+                // of the rectangle alone, and no ray from outside it can enter the box itself)
+                enters[j] = ft.accel && seesScene(fr, px, py) && tracer.entersScene(o[j], rcp3(d[j]));
                 // without the acceleration structure, or with spheres in the scene, every ray has work left
                 queue[j] = enters[j] || !ft.accel || sc.nSpheres != 0;
                 if (!queue[j]) {
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
     r.cur = kRefNone;
     r.pend = 0u;
     r.top = tracer.stk;
+    r.tos = kRefNone;
     r.nInner = r.nTris = 0;
     r.itInner = r.itLeaf = r.itRuns = 0;
     r.topHits[0] = r.topHits[1] = r.topHits[2] = 0;
@@ -661,19 +664,19 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
 // TRANSP: testVisibilityLightSampleTransparency (src/light.cpp:112-151) instead of the binary
 // test: the closest hit along the ray; a hit short of the shaded point on a material that is
 // not opaque tints the light and the ray goes on from there.
-#ifdef RT_SHADOW_WAVES // experiments: force the register budget of this many waves per SIMD
-#define RT_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WAVES, RT_SHADOW_WAVES)))
-#else
-#define RT_SHADOW_ATTR
+// Register budget: six waves per SIMD (80 registers) for both variants.  The plain one needs 79 to 81 depending
+// on details of the box test, and an 81st register would cost a sixth of the resident waves; the variant that
+// follows light through transparent surfaces needs a register or two more and keeps the budget at the price of a
+// spill outside the loop.  The counting builds take what they need.  (RT_SHADOW_WAVES, RT_TRANSP_WAVES: experiments.)
+#ifndef RT_SHADOW_WAVES
+#define RT_SHADOW_WAVES 6
 #endif
-// (the variant that follows light through transparent surfaces needs a register or two more than six
-// waves per SIMD leave it; held to that budget it keeps them, at the price of a spill outside the loop)
 #ifndef RT_TRANSP_WAVES
 #define RT_TRANSP_WAVES 6
 #endif
-#define RT_SHADOW_TRANSP_ATTR(on) __attribute__((amdgpu_waves_per_eu((on) ? RT_TRANSP_WAVES : 1)))
+#define RT_SHADOW_ATTR(stats, transp) __attribute__((amdgpu_waves_per_eu((stats) ? 1 : ((transp) ? RT_TRANSP_WAVES : RT_SHADOW_WAVES))))
 template <bool STATS, bool TRANSP>
-__global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR RT_SHADOW_TRANSP_ATTR(TRANSP && !STATS) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+__global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR(STATS, TRANSP) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
@@ -687,6 +690,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR RT_SHADOW_TRANSP_ATTR
     r.cur = kRefNone;
     r.pend = 0u;
     r.top = tracer.stk;
+    r.tos = kRefNone;
     r.nInner = r.nTris = 0;
     r.itInner = r.itLeaf = r.itRuns = 0;
     r.topHits[0] = r.topHits[1] = r.topHits[2] = 0;

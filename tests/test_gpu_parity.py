@@ -220,6 +220,36 @@ def test_render_matches_oracle(ctx, key):
     assert exact >= 0.999
 
 
+def test_scene_far_from_the_origin_with_an_environment_map():
+    """A scene a thousand units away from the origin, a few units across, seen face-on with the environment map
+    on: every pixel then has camera rays (the background has a colour of its own), and the widening of the root
+    box test against rounding, which grows with the coordinates, exceeds a pixel.  Rays of pixels outside the
+    rectangle the scene's box projects to must not be queued for traversal (the queue and the hit pools are sized
+    by the rectangle); rays, image and primary hits equal the oracle's, with one pixel sample and with nine."""
+    import copy
+    scn = copy.deepcopy(common.scene("Monkey", env_map=True))
+    shift = np.array([1000.0, -800.0, 1200.0], dtype=np.float32)
+    for m in scn.meshes:
+        m.vertices["position"] += shift
+    for l in scn.lights:
+        l["v"][0:3] += shift
+    osc = orc.OracleScene(scn)
+    for (w, h, spp, rot) in ((96, 64, 1, (0.0, 0.0, 0.0)), (64, 48, 9, (20.0, 20.0, 0.0)), (48, 64, 1, (90.0, 0.0, 0.0))):
+        cam = sio.default_camera(w, h, distance=6.0, look_at=tuple(float(x) for x in shift), rotation_deg=rot)
+        f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, enableEnvironmentMap=1,
+                            numPixelSamples=spp)
+        ref, st_o = osc.render(f, cam, w, h)
+        for env in (dict(per_pixel=0), dict(per_pixel=0, workspace_bytes=2 << 20)):
+            c = _ctx_with(**env)
+            c.upload_scene(scn)
+            c.set_features(f)
+            img, st = c.render(cam, w, h)
+            c.close()
+            maxabs, rmse = common.image_error(img, ref)
+            assert st["rays"] == st_o["rays"], (w, h, spp, env, st["rays"], st_o["rays"])
+            assert ref.any() and maxabs <= 2e-5 and rmse <= 2e-6, (w, h, spp, env, maxabs)
+
+
 def test_hundreds_of_camera_rays_per_pixel():
     """The sample counts of the largest configuration (64 pixel samples x 5 lens samples = 320 camera
     rays per pixel, area light x 4, transparency) and an odd count beyond 256 (17 x 17 = 289): a
