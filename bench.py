@@ -69,6 +69,7 @@ sharding = importlib.import_module("ray-tracer_amd.sharding")
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X vector FP32, spec (packed fused multiply-adds)
 SHADER_CLOCK_GHZ = 2.4    # MI355X peak engine clock (GRBM_GUI_ACTIVE / 8 XCDs / kernel time reads 2.4 - 2.5 under this load)
+L1_LOOKUPS_PER_CU_CLOCK = 1.10  # sixteen-byte loads of single lanes one compute unit's L1 serves per clock (profiles/round2_a_ta_probe.txt)
 
 
 def build_workload(name: str):
@@ -147,20 +148,34 @@ def stored_counters(workload, kernel, world, width, height, distance=3.0):
     kernel sources stored with them says whether they belong to the library that is running."""
     path = os.path.join(ROOT, "profiles", f"pmc_counters_{workload}.json")
     if world != 1 or distance != 3.0 or not os.path.exists(path):
-        return None, "no stored counter pass for this configuration"
+        return None, "no stored counter pass for this configuration", False
     _, _, w0, h0, _ = build_workload(workload)
     if (w0, h0) != (width, height):
-        return None, "no stored counter pass at this resolution"
+        return None, "no stored counter pass at this resolution", False
     with open(path) as fh:
         doc = json.load(fh)
     k = doc["kernels"].get(kernel)
     if k is None:
-        return None, "kernel not in the stored counter pass"
+        return None, "kernel not in the stored counter pass", False
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_summarise
     same = pmc_summarise.sources_sha1() == doc.get("sources_sha1")
     return k, (f"stored: profiles/{doc['summary']} ({doc['source']}); "
-               + ("collected on these kernel sources" if same else "the kernel sources have changed since"))
+               + ("collected on these kernel sources" if same else "the kernel sources have changed since")), same
+
+
+def valu_probe_peak(waves_per_simd=6):
+    """The vector ALU's measured issue rate for the instruction mix of one traversal step (tools/valu_probe.hip,
+    stored as profiles/valu_probe_gfx950.json), at the shadow kernel's occupancy."""
+    path = os.path.join(ROOT, "profiles", "valu_probe_gfx950.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rows = json.load(fh)["rows"]
+    for r in rows:
+        if r["stream"].startswith("mix of one sibling-pair step") and r["waves_per_simd"] == waves_per_simd:
+            return r
+    return None
 
 
 def launch_ranks(n: int) -> int:
@@ -367,6 +382,17 @@ def main():
     cst = ctx.render_device(camera, width, height, tmp.data_ptr(), tmp.numel(), rank if world > 1 else 0, world,
                             streams[0].cuda_stream, collect_stats=True)
 
+    # N > 1: the frame rank 0 put together from the gathered shards against the same frame rendered whole by one
+    # rank (pixels are independent, so the two must agree bit for bit); outside the timed region
+    frame_equal = None
+    if world > 1 and rank == 0:
+        last = (args.warmup + args.steps - 1) % lanes
+        whole = torch.empty(width * height * 3, dtype=torch.float32, device=dev)
+        ctx.render_device(camera, width, height, whole.data_ptr(), whole.numel(), 0, 1, streams[0].cuda_stream)
+        ctx.sync(streams[0].cuda_stream)
+        torch.cuda.synchronize(dev)
+        frame_equal = bool(torch.equal(whole.view(torch.int32), frames[last].view(torch.int32)))
+
     if rank == 0:
         ms_per_step = dt_max / args.steps * 1e3
         value = rays_total * args.steps / dt_max / 1e6
@@ -382,31 +408,48 @@ def main():
             k_rays, k_inner, k_tris = cst["rays"], cst["inner_nodes"], cst["tri_tests"]
         k_alone = (alone["shadow_ms"] / per_frame if shadow_ms > 0 else alone["kernel_ms"]) / max(1, alone["launches"])
         t_alone = max(k_alone, 1e-9) * 1e-3  # seconds one launch takes with the chip to itself
-        # What bounds the kernel is the issue of vector-ALU instructions: a 64-lane wave-instruction holds
-        # one of the 4 x 256 SIMDs for four clocks, and the traversal loop is arithmetic from end to end
-        # (byte permutes, fmas, min/max, compares; profiles/round2_b_*: taking two thirds of its loads off
-        # the vector memory path changes nothing, halving the resident waves costs a third).  The count of
-        # issued wave-instructions is a hardware counter (SQ_INSTS_VALU), which rocprofv3 cannot collect
-        # inside this process: it comes from the committed counter pass over this same launch, the time
-        # from this run's HIP events around the launch on a stream it has to itself.
-        ctrs, ctr_src = stored_counters(args.workload, kname, world, width, height, args.camera_distance)
-        valu_peak = 4 * num_cu * SHADER_CLOCK_GHZ / 4.0  # G wave-instructions / s
-        roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": round(valu_peak, 1),
-                "peak_is": f"{4 * num_cu} SIMDs x {SHADER_CLOCK_GHZ} GHz / 4 clocks per 64-lane instruction",
+        # What bounds the kernel, as measured (profiles/round3_c_sensitivity.txt: work of one kind added to every
+        # traversal step): the vector memory path.  Every lane's 16-byte load is one lookup in the compute unit's
+        # L1, which serves about one a clock (tools/ta_probe.hip: 1.10 per CU-clock for two loads per 32-byte
+        # record out of an L1-resident table, 0.78 out of an L2-resident one); added loads cost nearly in
+        # proportion, added vector or scalar instructions a tenth of theirs.  So `achieved` / `peak` are lookups
+        # per second against the probe's L1-resident rate.  The vector ALU's own figure rides along
+        # (`valu_issue`): wave-instructions issued against the rate the probe measures for the instruction mix
+        # of one traversal step at the kernel's six waves per SIMD (tools/valu_probe.hip: multiply-adds, adds,
+        # moves and bit operations issue every 2.2-2.4 clocks of a SIMD, permutes, minima, compares, selects
+        # and conversions every 4.1; one wave alone issues every 5-8 clocks whatever the instruction).
+        # Counters (TCP_TOTAL_CACHE_ACCESSES, SQ_INSTS_VALU) cannot be collected inside this process: they come
+        # from the committed counter pass over this same launch and count only if it ran on these kernel
+        # sources; the time is this run's HIP events around the launch on a stream it has to itself.
+        ctrs, ctr_src, ctr_fresh = stored_counters(args.workload, kname, world, width, height, args.camera_distance)
+        l1_peak = L1_LOOKUPS_PER_CU_CLOCK * num_cu * SHADER_CLOCK_GHZ  # G lookups / s
+        roof = {"bound": "l1_lookups", "unit": "G lookups/s", "peak": round(l1_peak, 1),
+                "peak_is": f"{num_cu} compute units x {L1_LOOKUPS_PER_CU_CLOCK} sixteen-byte lane-loads per clock (measured, "
+                           f"profiles/round2_a_ta_probe.txt, L1-resident table) x {SHADER_CLOCK_GHZ} GHz",
                 "achieved": None, "frac": None, "counters": ctr_src, "traffic": None}
-        if ctrs and ctrs.get("SQ_INSTS_VALU"):
-            valu = ctrs["SQ_INSTS_VALU"]
-            roof["achieved"] = round(valu / t_alone / 1e9, 2)
-            roof["frac"] = round(valu / t_alone / 1e9 / valu_peak, 4)
-            roof["valu_wave_instructions_per_launch"] = valu
-            roof["valu_wave_instructions_per_ray"] = round(valu / max(1.0, k_rays), 2)
-            if ctrs.get("SQ_THREAD_CYCLES_VALU"):
-                roof["lanes_per_valu"] = round(ctrs["SQ_THREAD_CYCLES_VALU"] / valu, 1)
+        if ctrs and not ctr_fresh:
+            roof["stale_counters"] = "the stored counter pass ran on other kernel sources: no achieved / frac from it"
+        if ctrs and ctr_fresh:
             if ctrs.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
                 acc = ctrs["TCP_TOTAL_CACHE_ACCESSES_sum"]
-                roof["l1_lookups"] = {"per_ray": round(acc / max(1.0, k_rays), 1),
-                                      "per_cu_clock": round(acc / t_alone / (num_cu * SHADER_CLOCK_GHZ * 1e9), 3),
-                                      "note": "one per 16-byte load of one lane; a compute unit serves about one a clock (profiles/round2_a_ta_probe.txt)"}
+                roof["achieved"] = round(acc / t_alone / 1e9, 2)
+                roof["frac"] = round(acc / t_alone / 1e9 / l1_peak, 4)
+                roof["l1_lookups_per_ray"] = round(acc / max(1.0, k_rays), 1)
+                roof["l1_lookups_per_cu_clock"] = round(acc / t_alone / (num_cu * SHADER_CLOCK_GHZ * 1e9), 3)
+                if ctrs.get("TCP_TCC_READ_REQ_sum"):
+                    roof["l1_miss_rate"] = round(ctrs["TCP_TCC_READ_REQ_sum"] / acc, 3)
+            if ctrs.get("SQ_INSTS_VALU"):
+                valu = ctrs["SQ_INSTS_VALU"]
+                vp = valu_probe_peak()
+                vi = {"unit": "G wave-instructions/s", "achieved": round(valu / t_alone / 1e9, 2),
+                      "valu_wave_instructions_per_launch": valu, "valu_wave_instructions_per_ray": round(valu / max(1.0, k_rays), 2)}
+                if vp:
+                    vi.update({"peak": vp["chip_G_wave_instructions_per_s"], "frac": round(valu / t_alone / 1e9 / vp["chip_G_wave_instructions_per_s"], 4),
+                               "peak_is": f"measured: '{vp['stream']}' at {vp['waves_per_simd']} waves per SIMD, {vp['per_simd_clock']} "
+                                          f"wave-instructions per SIMD-clock at {vp['shader_clock_GHz']} GHz (profiles/valu_probe_gfx950.json)"})
+                if ctrs.get("SQ_THREAD_CYCLES_VALU"):
+                    vi["lanes_per_valu"] = round(ctrs["SQ_THREAD_CYCLES_VALU"] / valu, 1)
+                roof["valu_issue"] = vi
             if "fetch_bytes" in ctrs and "write_bytes" in ctrs:
                 roof["traffic"] = ctrs["fetch_bytes"] + ctrs["write_bytes"]
         # The two figures the scope table asks for, on the same launch alone.  Algorithmic traffic: 64 B per
@@ -443,7 +486,8 @@ def main():
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "rays_per_frame": int(rays_total),
-                       "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)", "frames_in_flight": lanes, **({"ctx_options": args.ctx_option} if args.ctx_option else {}),
+                       "tile_sharding": f"8x8 tiles interleaved over {world} GPU(s)", "frames_in_flight": lanes,
+                       **({"gathered_frame_equals_one_rank_frame": frame_equal} if frame_equal is not None else {}), **({"ctx_options": args.ctx_option} if args.ctx_option else {}),
                        "scene_note": "dragon.obj is absent from the reference snapshot; procedural stand-in with the same triangle count"},
             "roofline": roof,
         }

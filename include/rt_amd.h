@@ -262,7 +262,10 @@ int rt_scene_upload(rt_ctx* ctx, const rt_node* nodes, uint32_t n_nodes, const r
 
 /* scene.lights (src/scene.h:36) and the Features argument of renderImage;
  * cheap, may be re-sent before every frame (the GUI mutates both between
- * calls, src/main.cpp:179-270,340-418). */
+ * calls, src/main.cpp:179-270,340-418).  rt_lights_set copies the lights to
+ * the device before it returns (to one of four slots in turn; frames already
+ * enqueued keep reading the slot they were enqueued with, so it does not wait
+ * for them unless four further calls have come round to their slot). */
 int rt_lights_set(rt_ctx* ctx, const rt_light* lights, uint32_t n);
 int rt_features_set(rt_ctx* ctx, const rt_features* features);
 
@@ -297,6 +300,9 @@ size_t rt_shard_floats(int width, int height, int shard_index, int shard_count);
  * than the scratch (hundreds of camera rays per pixel times many light samples at a deep ray depth)
  * and, with bloom on and shard_count == 1, a frame whose copy (width * height * 12 bytes) does not
  * fit.  No timing is taken (events are allocations); rt_sync still returns the ray count.  The
+ * call can be recorded into a HIP graph by stream capture and replayed (it enqueues kernels and
+ * memsets on `stream`, nothing else): the graph keeps the scene, lights, features, camera and
+ * output pointer it was recorded with; set lights outside the capture only.  The
  * scratch is one per GPU, not per context: calls that overlap on one GPU (two streams, two contexts)
  * race, and so do a call here and the stats read of an earlier one. */
 #define RT_NOALLOC_SCRATCH_BYTES ((size_t)128 << 20)

@@ -90,10 +90,20 @@ struct rt_ctx {
     DevTex* dTexs = nullptr;
     float* dTexels = nullptr;
     DevSphere* dSpheres = nullptr;
+    // Lights on the device: kLightSlots copies' worth of room in one allocation.  rt_lights_set writes the NEXT slot,
+    // at once, over a stream of the context's own, and frames enqueued from then on are handed that slot's address;
+    // frames enqueued before keep the slot they were given.  So a render call enqueues no copy from the caller's
+    // (pageable) memory, which is what a HIP graph recorded from it could not replay, and re-sending the lights does
+    // not wait for frames in flight.  A slot comes round again after kLightSlots calls; the event recorded behind the
+    // last frame that read it is waited for first.
+    static constexpr int kLightSlots = 4;
     rt_light* dLights = nullptr;
-    uint32_t lightCap = 0;
+    uint32_t lightCap = 0; // lights per slot
+    int lightSlot = 0;     // the slot the next frame reads
+    hipEvent_t lightSlotUsed[kLightSlots] = {};
+    bool lightSlotPending[kLightSlots] = {};
+    hipStream_t copyStream = nullptr;
     std::vector<rt_light> hostLights;
-    bool lightsDirty = false; // hostLights not yet copied to dLights
     bool anyMirror = true, anyClear = true, anyMirrorAndClear = true; // what the scene's materials can ask of a hit
     DevCounters* dCounters = nullptr;
     float* dFrame = nullptr;
@@ -158,6 +168,8 @@ struct rt_ctx {
     // ordinal beyond the table
     void* scratchPtr = nullptr;
     DevCounters* lastCounters = nullptr; // where the last render's counters live (dCounters or the scratch)
+    size_t wsClamp = 0;                  // the working-memory limit a frame was last cut down to (0 = none) and the scene it held for
+    uint64_t wsClampGeneration = 0;
     // resident blocks per compute unit of the kernels the current scene and features select, asked
     // of the runtime when either changes so that a render call has nothing left to ask
     struct Occupancy {
@@ -235,14 +247,21 @@ static int foldTimings(rt_ctx* ctx)
     return RT_OK;
 }
 
-// The lights last set, copied to the device in the order of `stream` (no-op when they are there already).
-static int flushLights(rt_ctx* ctx, hipStream_t stream)
+// Behind the launches of a frame: marks the slot of lights they read as in use until they have run (see rt_ctx).
+// Nothing is recorded on a stream that is being captured into a graph: the graph replays with the slot it was
+// recorded with, and whoever replays it keeps the lights as they were.
+static int lightsUsedBy(rt_ctx* ctx, hipStream_t stream)
 {
-    if (!ctx->lightsDirty)
+    if (!ctx->dLights)
         return RT_OK;
-    if (!ctx->hostLights.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->dLights, ctx->hostLights.data(), ctx->hostLights.size() * sizeof(rt_light), hipMemcpyHostToDevice, stream));
-    ctx->lightsDirty = false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return RT_OK;
+    hipEvent_t& ev = ctx->lightSlotUsed[ctx->lightSlot];
+    if (!ev)
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ev, stream));
+    ctx->lightSlotPending[ctx->lightSlot] = true;
     return RT_OK;
 }
 
@@ -393,6 +412,11 @@ void rt_ctx_destroy(rt_ctx* ctx)
             (void)hipFree(p);
     if (ctx->wsBase)
         (void)hipFree(ctx->wsBase);
+    for (hipEvent_t e : ctx->lightSlotUsed)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (ctx->copyStream)
+        (void)hipStreamDestroy(ctx->copyStream);
     for (hipEvent_t e : ctx->markPool)
         (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->evPool)
@@ -920,9 +944,12 @@ try {
         if (ctx->treeBuildOnDevice) {
             HIP_TRY(ctx, hipSetDevice(ctx->device));
             std::string err;
-            if (!deviceOwnTree(leaves, grid, pairs, rootRef, maxLevel, err))
+            const int built = deviceOwnTree(leaves, grid, pairs, rootRef, maxLevel, err);
+            if (built == kTreeFailed)
                 return fail(ctx, RT_ERR_DEVICE, "rt_scene_upload: %s", err.c_str());
-            ownTree = true;
+            // a shape the traversal cannot take: the host's builder has its say, then the caller's own nodes,
+            // exactly as without the option (results do not depend on which tree is traversed)
+            ownTree = built == kTreeBuilt || buildOwnTree(leaves, grid, pairs, rootRef, maxLevel);
         } else {
             ownTree = buildOwnTree(leaves, grid, pairs, rootRef, maxLevel);
         }
@@ -1111,18 +1138,32 @@ try {
         if (lights[i].type < 0 || lights[i].type > 2)
             return fail(ctx, RT_ERR_INVALID, "rt_lights_set: light %u has type %d", i, lights[i].type);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copyStream)
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking));
     if (n > ctx->lightCap || !ctx->dLights) {
         HIP_TRY(ctx, hipDeviceSynchronize());
         if (ctx->dLights)
             (void)hipFree(ctx->dLights);
+        ctx->dLights = nullptr;
         ctx->lightCap = std::max<uint32_t>(n, 16);
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->dLights), ctx->lightCap * sizeof(rt_light)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->dLights), static_cast<size_t>(rt_ctx::kLightSlots) * ctx->lightCap * sizeof(rt_light)));
+        for (bool& pending : ctx->lightSlotPending)
+            pending = false;
     }
-    // The lights reach the device with the next call that reads them, as a copy enqueued on that call's
-    // own stream: frames already enqueued there keep the lights they were enqueued with.
+    // The next slot, written now (frames already enqueued keep the slot they were enqueued with; see rt_ctx).
+    const int slot = (ctx->lightSlot + 1) % rt_ctx::kLightSlots;
+    if (ctx->lightSlotPending[slot]) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->lightSlotUsed[slot]));
+        ctx->lightSlotPending[slot] = false;
+    }
+    rt_light* dst = ctx->dLights + static_cast<size_t>(slot) * ctx->lightCap;
+    if (n) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, lights, n * sizeof(rt_light), hipMemcpyHostToDevice, ctx->copyStream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->copyStream));
+    }
+    ctx->lightSlot = slot;
     ctx->hostLights.assign(lights, lights + n);
-    ctx->lightsDirty = true;
-    ctx->scene.lights = ctx->dLights;
+    ctx->scene.lights = dst;
     ctx->scene.nLights = static_cast<int32_t>(n);
     return RT_OK;
 } catch (...) {
@@ -1436,11 +1477,6 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
             return fail(ctx, RT_ERR_INTERNAL, "render: scratch smaller than the counters");
     }
     ctx->lastCounters = dCounters;
-    {
-        const int rl = flushLights(ctx, stream);
-        if (rl != RT_OK)
-            return rl;
-    }
     HIP_TRY(ctx, hipMemsetAsync(dCounters, 0, collect ? sizeof(DevCounters) : offsetof(DevCounters, waveLog), stream));
     if (timeIt) {
         if (ctx->evUsed + 2 > ctx->evPool.size()) {
@@ -1653,7 +1689,11 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         };
         // (RT_OPT_WORKSPACE_BYTES caps what grows with the batch; memory that is really there -- an arena, or
         // what the device has free, below -- has to hold the fixed part as well)
-        if (!plan(workspaceCap, arena ? fixedBytes : 0))
+        // (a frame that had to be cut down to the memory the device had left is planned under that limit again, so that
+        // the plan kept from it is found and its workspace is not given back and asked for anew frame after frame;
+        // the limit is forgotten with the scene)
+        const bool clamped = !arena && ctx->wsClamp != 0 && ctx->wsClampGeneration == ctx->generation;
+        if (!plan(clamped ? std::min<uint64_t>(workspaceCap, ctx->wsClamp) : workspaceCap, (arena || clamped) ? fixedBytes : 0))
             return fail(ctx, RT_ERR_UNSUPPORTED, "render: one 8x8 tile of this frame needs %llu bytes of working memory, more than the %zu-byte %s",
                 static_cast<unsigned long long>(64 * (perSlot + perCand) + fixedBytes), workspaceCap, arena ? "scratch left" : "workspace");
         size_t total = sizes();
@@ -1671,6 +1711,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                         return fail(ctx, RT_ERR_DEVICE, "render: %zu bytes of device memory are free, one 8x8 tile of this frame needs %llu",
                             freeB, static_cast<unsigned long long>(64 * (perSlot + perCand) + fixedBytes));
                     total = sizes();
+                    ctx->wsClamp = allowed;
+                    ctx->wsClampGeneration = ctx->generation;
                 }
                 HIP_TRY(ctx, hipStreamSynchronize(stream)); // (frames still in flight on this stream use the old buffer)
                 if (ctx->wsBase)
@@ -1758,7 +1800,7 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         HIP_TRY(ctx, hipEventRecord(ctx->evPool[ctx->evUsed + 1], stream));
         ctx->evUsed += 2;
     }
-    return RT_OK;
+    return lightsUsedBy(ctx, stream);
 }
 
 static int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
@@ -2022,6 +2064,17 @@ try {
         std::memset(stats, 0, sizeof *stats);
         return readStats(ctx, stats, true);
     }
+    // No statistics asked for: the one counter that says whether the frame is valid is looked at all the same.
+    if (ctx->lastCounters) {
+        unsigned long long overflow = 0;
+        HIP_TRY(ctx, hipMemcpy(&overflow, reinterpret_cast<const char*>(ctx->lastCounters) + offsetof(DevCounters, overflow), sizeof overflow,
+            hipMemcpyDeviceToHost));
+        if (overflow) {
+            ctx->evUsed = ctx->marksUsed = 0;
+            return fail(ctx, RT_ERR_INTERNAL, "render: %llu hits found no slot in the hit pool (the frame is invalid; this is a bug in the pool's sizing)",
+                overflow);
+        }
+    }
     return RT_OK;
 } catch (...) {
     return caught(ctx, "rt_sync");
@@ -2130,11 +2183,6 @@ try {
         std::memset(&f, 0, sizeof f);
     const DevFeat ft = makeFeat(f);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    {
-        const int rl = flushLights(ctx, nullptr);
-        if (rl != RT_OK)
-            return rl;
-    }
     float *dIn = nullptr, *dOut = nullptr;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dIn), inFloats * sizeof(float)));
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&dOut), outFloats * sizeof(float));

@@ -119,7 +119,7 @@ __device__ __forceinline__ float halfArea(const float* lo, const float* hi)
 }
 
 __global__ __launch_bounds__(64) void splitKernel(Node* __restrict__ nodes, uint32_t levelBase, uint32_t levelCount, const Bin* __restrict__ bins,
-    uint4* __restrict__ pairs, uint32_t* __restrict__ nextNode, uint32_t* __restrict__ maxDepth, QuantGrid grid, int maxStack)
+    uint4* __restrict__ pairs, uint32_t* __restrict__ nextNode, uint32_t* __restrict__ maxDepth, QuantGrid grid, int maxStack, uint32_t capacity)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= levelCount)
@@ -187,6 +187,11 @@ __global__ __launch_bounds__(64) void splitKernel(Node* __restrict__ nodes, uint
         grid.packBox(bl[s], bh[s], w[s]);
         if (sideItems[s] >= 2u) {
             const uint32_t c = atomicAdd(nextNode, 1u);
+            if (c >= capacity) { // cannot happen with n items (at most n - 1 inner nodes); the host sees the count and gives up
+                nd.child[s] = kNoChild;
+                refs[s] = kRefNone;
+                continue;
+            }
             Node ch {};
             for (int a = 0; a < 3; a++)
                 ch.lo[a] = bl[s][a], ch.hi[a] = bh[s][a];
@@ -257,23 +262,25 @@ struct Buffers {
         const hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess) {                                                                              \
             error = std::string(#expr) + " failed: " + hipGetErrorString(e_);                                \
-            return false;                                                                                    \
+            return kTreeFailed;                                                                              \
         }                                                                                                    \
     } while (0)
 
-bool deviceOwnTree(const std::vector<TreeLeaf>& leaves, const QuantGrid& grid, std::vector<uint4>& pairs, uint32_t& rootRef,
+// Returns kTreeBuilt, kTreeUnusable (the tree came out in a shape the traversal cannot take, e.g. deeper than its stack:
+// the caller builds another way) or kTreeFailed (a HIP call failed); `error` says what happened.
+int deviceOwnTree(const std::vector<TreeLeaf>& leaves, const QuantGrid& grid, std::vector<uint4>& pairs, uint32_t& rootRef,
     uint32_t& levels, std::string& error)
 {
     const uint32_t n = static_cast<uint32_t>(leaves.size());
     pairs.clear();
     if (n == 0) {
         error = "no leaves";
-        return false;
+        return kTreeUnusable;
     }
     if (n == 1) {
         rootRef = leaves[0].ref;
         levels = 1;
-        return true;
+        return kTreeBuilt;
     }
     std::vector<Item> host(n);
     Node root {};
@@ -315,24 +322,24 @@ bool deviceOwnTree(const std::vector<TreeLeaf>& leaves, const QuantGrid& grid, s
     for (int guard = 0; levelEnd > levelBase; guard++) {
         if (guard > 2 * kMaxStack) {
             error = "device tree build did not terminate";
-            return false;
+            return kTreeUnusable;
         }
         const uint32_t count = levelEnd - levelBase;
         if (count > maxPerLevel) {
             error = "device tree build: more nodes on a level than items allow";
-            return false;
+            return kTreeUnusable;
         }
         const uint32_t nBins = count * 3u * kBins;
         hipLaunchKernelGGL(clearBinsKernel, dim3((nBins + 255u) / 256u), dim3(256), 0, 0, dBins, nBins);
         hipLaunchKernelGGL(binKernel, dim3(itemGrid), dim3(256), 0, 0, dItems, n, dItemNode, dNodes, levelBase, dBins);
         hipLaunchKernelGGL(splitKernel, dim3((count + 63u) / 64u), dim3(64), 0, 0, dNodes, levelBase, count, dBins, dPairs, dCounters, dCounters + 1,
-            grid, kMaxStack);
+            grid, kMaxStack, n);
         hipLaunchKernelGGL(moveKernel, dim3(itemGrid), dim3(256), 0, 0, dItems, n, dItemNode, dNodes, reinterpret_cast<uint32_t*>(dPairs));
         uint32_t c[2];
         TREE_TRY(hipMemcpy(c, dCounters, sizeof c, hipMemcpyDeviceToHost));
         if (c[0] > n) {
             error = "device tree build: node numbers ran past the item count";
-            return false;
+            return kTreeUnusable;
         }
         levelBase = levelEnd;
         levelEnd = c[0];
@@ -344,9 +351,9 @@ bool deviceOwnTree(const std::vector<TreeLeaf>& leaves, const QuantGrid& grid, s
     rootRef = 0;
     if (levels + 1 > (uint32_t)kMaxStack) {
         error = "device tree deeper than a traversal stack";
-        return false;
+        return kTreeUnusable;
     }
-    return true;
+    return kTreeBuilt;
 }
 
 } // namespace rt

@@ -54,8 +54,11 @@ struct QuantGrid {
 
 // The hierarchy over `leaves` built on the current HIP device with the binned surface-area heuristic
 // (32 bins per axis over the node's box, all nodes of a level at once): sibling-pair records in
-// breadth-first order, as buildOwnTree makes them.  False with `error` set on failure.
-bool deviceOwnTree(const std::vector<TreeLeaf>& leaves, const QuantGrid& grid, std::vector<uint4>& pairs, uint32_t& rootRef,
+// breadth-first order, as buildOwnTree makes them.  kTreeUnusable: the tree came out in a shape the
+// traversal cannot take (deeper than its stack), the caller builds another way; kTreeFailed: a HIP call
+// failed.  `error` says what happened in either case.
+enum : int { kTreeBuilt = 0, kTreeUnusable = 1, kTreeFailed = 2 };
+int deviceOwnTree(const std::vector<TreeLeaf>& leaves, const QuantGrid& grid, std::vector<uint4>& pairs, uint32_t& rootRef,
     uint32_t& levels, std::string& error);
 
 } // namespace rt

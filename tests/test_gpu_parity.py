@@ -668,6 +668,28 @@ def test_sharded_render_equals_whole_frame(ctx):
         assert np.array_equal(sharding.deinterleave(packed.cpu().numpy(), w, h, world).view(np.uint32), whole.view(np.uint32))
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_n_rank_step_puts_the_one_rank_frame_together(world):
+    """bench.py's own N > 1 branch -- its step function with its frames in flight (four at two ranks, six from
+    four ranks on), the packed shard buffers, the gather, rank 0's de-interleave and post-process -- run on one
+    GPU as rank 0 of a world whose collectives are stand-ins (tools/mock_world.py --all-shards: the gather's
+    stand-in renders the other ranks' shards).  The frame rank 0 ends up with must equal, bit for bit, the
+    frame one rank renders whole."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "mock_world.py"), str(world), "--all-shards", "--steps", "7",
+                          "--warmup", "2", "--no-cpu", "--width", "480", "--height", "272"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    cfg = lines[0]["config"]
+    assert lines[0]["n_gpus"] == world and cfg["frames_in_flight"] == (4 if world < 4 else 6)
+    assert cfg["gathered_frame_equals_one_rank_frame"] is True
+
+
 def test_error_behaviour(ctx):
     fresh = capi.Context(0)
     with pytest.raises(capi.RtError) as e:

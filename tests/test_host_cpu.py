@@ -189,7 +189,7 @@ def test_world_size_2_tile_gather_over_gloo(tmp_path):
     assert "GLOO_OK" in out.stdout
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 4, 8])
 def test_bench_starts_its_own_ranks(n):
     """`python bench.py --gpus N` with no launcher around it: the parent starts torch.distributed.run
     as a child before touching the GPU, the ranks rendezvous (gloo here), gather their tiles, reduce

@@ -34,14 +34,14 @@ def collect(root: str):
 
 
 def sources_sha1() -> str:
-    """Hash of the kernel sources: tells bench.py whether stored counters belong to the library it runs."""
+    """Hash of the sources the queue-based renderer's kernels are compiled from (rt_wavefront.hip and what it
+    includes): tells bench.py whether stored counters belong to the kernels it runs."""
     import hashlib
     here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray-tracer_amd", "csrc")
     h = hashlib.sha1()
-    for f in sorted(os.listdir(here)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(here, f), "rb").read())
+    for f in ("rt_device.hpp", "rt_fastdiv.hpp", "rt_pow.hpp", "rt_trace.hpp", "rt_trig.hpp", "rt_wavefront.hip", "rt_wavefront.hpp"):
+        h.update(f.encode())
+        h.update(open(os.path.join(here, f), "rb").read())
     return h.hexdigest()
 
 
