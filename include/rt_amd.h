@@ -194,7 +194,7 @@ void rt_ctx_destroy(rt_ctx* ctx);
  *                           and triangle tests (src/bvh.cpp:245-316).  A cross-check: by default only rays
  *                           are replayed that met equal distances, or whose hit the reference's box routine
  *                           (which loses hits by rounding) may have kept it from; the answers are the same.
- *  RT_OPT_WORKSPACE_BYTES   cap on the working memory of the queue-based renderer (default 64 GiB, never more
+ *  RT_OPT_WORKSPACE_BYTES   cap on the working memory of the queue-based renderer (default 192 GiB, never more
  *                           than the device has free); a frame that needs more is rendered in pixel batches.
  *  RT_OPT_TIMING            0 = record no events around the render launches (rt_stats times read 0).
  *  RT_OPT_TREE_BUILD        who builds the library's own hierarchy at rt_scene_upload: 0 (default) the host, sweeping
