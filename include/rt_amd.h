@@ -300,9 +300,8 @@ size_t rt_shard_floats(int width, int height, int shard_index, int shard_count);
  * than the scratch (hundreds of camera rays per pixel times many light samples at a deep ray depth)
  * and, with bloom on and shard_count == 1, a frame whose copy (width * height * 12 bytes) does not
  * fit.  No timing is taken (events are allocations); rt_sync still returns the ray count.  The
- * call can be recorded into a HIP graph by stream capture and replayed (it enqueues kernels and
- * memsets on `stream`, nothing else): the graph keeps the scene, lights, features, camera and
- * output pointer it was recorded with; set lights outside the capture only.  The
+ * call enqueues kernels and memsets on `stream`, nothing else; replaying it from a HIP graph is not
+ * claimed (it worked in a process of its own and faulted after other work in one process).  The
  * scratch is one per GPU, not per context: calls that overlap on one GPU (two streams, two contexts)
  * race, and so do a call here and the stats read of an earlier one. */
 #define RT_NOALLOC_SCRATCH_BYTES ((size_t)128 << 20)

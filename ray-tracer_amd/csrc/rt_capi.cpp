@@ -1502,7 +1502,11 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         && ctx->occ.variant == perPixelVariant(F, false);
     if (arena && !occReady)
         return fail(ctx, RT_ERR_STATE, "render: launch geometry not prepared (rt_scene_upload and rt_features_set do that)");
-    const bool perPixel = ctx->forcePerPixel || (F.enableGlossyReflection && F.enableReflections) || motionBlurOn(F);
+    // Glossy reflections take the queue-based renderer too (a tree kernel walks each pixel's radiance rays, everything
+    // else is shared with the mirror case), except together with transparency, which only the per-pixel kernel combines.
+    const bool glossyOn = F.enableGlossyReflection && F.enableReflections;
+    const bool glossyWf = glossyOn && !ctx->forcePerPixel && !F.enableTransparency && !motionBlurOn(F);
+    const bool perPixel = ctx->forcePerPixel || (glossyOn && !glossyWf) || motionBlurOn(F);
     if (perPixel) {
         const int variant = perPixelVariant(F, collect);
         int perCU = ctx->blocksPerCU;
@@ -1546,10 +1550,13 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         const bool dof = F.enableDepthOfField != 0;
         int pathPerCU = 0, shadowPerCU = 0, pathBlocksFixed = 0;
         const bool transp = F.enableTransparency != 0;
+        wp.absDraws = glossyWf ? 1u : 0u;
         if (occReady)
             pathPerCU = ctx->occ.path, shadowPerCU = ctx->occ.shadow;
         else
             HIP_TRY(ctx, wavefrontOccupancy(collect, transp, blockThreads, lds, &pathPerCU, &shadowPerCU));
+        if (glossyWf) // (the tree kernel stands in the path kernel's place; asking is no allocation)
+            HIP_TRY(ctx, glossyOccupancy(dof, collect, blockThreads, lds, &pathPerCU));
         if (pathPerCU < 1 || shadowPerCU < 1)
             return fail(ctx, RT_ERR_DEVICE, "render: the traversing kernels do not fit a compute unit (%zu B of LDS)", lds);
         pathPerCU = std::min(pathPerCU, maxPerCU), shadowPerCU = std::min(shadowPerCU, maxPerCU);
@@ -1603,7 +1610,17 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         // (src/recursive.cpp:43-63): a chain of maxRayDepth + 1 hits, unless some material asks for both.
         const bool mirrors = F.enableReflections && ctx->anyMirror, passes = transp && ctx->anyClear;
         uint64_t nodesPerPath = 1;
-        if (mirrors && passes && ctx->anyMirrorAndClear)
+        if (glossyWf) {
+            // every hit below the depth cap fans out into numGlossySamples children (src/extra.cpp:348-362), each a hit or,
+            // with an environment map, a node that carries the colour it left the scene with
+            if (mirrors) {
+                uint64_t level = 1;
+                for (int d = 0; d < F.maxRayDepth && nodesPerPath < (1ull << 40); d++) {
+                    level *= std::max<uint64_t>(1, F.numGlossySamples);
+                    nodesPerPath += F.numGlossySamples ? level : 0;
+                }
+            }
+        } else if (mirrors && passes && ctx->anyMirrorAndClear)
             nodesPerPath = (2ull << F.maxRayDepth) - 1;
         else if (mirrors || passes)
             nodesPerPath = static_cast<uint64_t>(F.maxRayDepth) + 1;
@@ -1786,9 +1803,14 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
                 marks = &ctx->markPool[ctx->marksUsed + 1];
                 ctx->marksUsed += 4;
             }
-            HIP_TRY(ctx, launchWavefront(dof, collect, transp, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
-                              wb, dCounters, dOut, traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB),
-                              traceKnobs(ctx->minActiveShadow, ctx->parkAShadow, ctx->parkBShadow), marks, ctx->numCU));
+            if (glossyWf)
+                HIP_TRY(ctx, launchWavefrontGlossy(dof, collect, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
+                                  wb, dCounters, dOut, traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB),
+                                  traceKnobs(ctx->minActiveShadow, ctx->parkAShadow, ctx->parkBShadow), marks, ctx->numCU));
+            else
+                HIP_TRY(ctx, launchWavefront(dof, collect, transp, pathBlocks, shadowBlocks, blockThreads, lds, stream, ctx->scene, cam, ft, fr, wp,
+                                  wb, dCounters, dOut, traceKnobs(ctx->minActive, ctx->parkA, ctx->parkB),
+                                  traceKnobs(ctx->minActiveShadow, ctx->parkAShadow, ctx->parkBShadow), marks, ctx->numCU));
         }
     }
     if (nShard == 1) { // a shard has no neighbours: a sharded frame is post-processed after its gather (rt_postprocess_device)

@@ -495,6 +495,277 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
 }
 
 // ---------------------------------------------------------------------------
+// 1c. glossy reflections (src/extra.cpp:329-368): the ray tree of a whole pixel, one lane per pixel.
+//     A glossy bounce fans out into numGlossySamples children whose directions are DRAWN, each child's
+//     two draws coming after everything its elder sibling's subtree drew -- so which rays a pixel has
+//     depends on the draws, and every ray of the pixel on all the rays before it in the recursion's
+//     order (src/recursive.cpp:25-64): that order is walked here, ray by ray, by one lane.  But only the
+//     rays that carry radiance (camera and glossy rays) are bound that way.  What a hit draws for its
+//     light samples is a fixed number of draws at a position known the moment the hit is made, so the
+//     kernel only writes the tree down -- a node per hit with the position of its draws, its first child
+//     and its next sibling -- and the light samples of all hits (most of a frame's rays), their shading
+//     and the sums are left to the coherent kernels below, as for mirror reflections.
+//     Frames of a lane's walk (the hits that still have children to come) sit in LDS, one per depth.
+// ---------------------------------------------------------------------------
+template <bool DOF, bool STATS>
+__global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene sc, const DevCamera cam,
+    const DevFeat ft, const DevFrame fr, const WfParams wp, const WfBuffers wb, DevCounters* __restrict__ ctr, int minActive)
+{
+    extern __shared__ uint32_t stackMem[];
+    const Tracer<STATS> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = wp.nSlots; // work items are the batch's pixel slots
+    uint32_t nodeBlock = wp.nodeBlockMax;
+    while (wp.nodeBlockFixed == 0u && nodeBlock > 64u && nodeBlock * (gridDim.x * (blockDim.x / 64u)) > 2u * total * wp.R)
+        nodeBlock >>= 1;
+
+    RayState r;
+    r.active = false;
+    r.cur = kRefNone;
+    r.pend = 0u;
+    r.top = tracer.stk;
+    r.tos = kRefNone;
+    r.nInner = r.nTris = 0;
+    r.itInner = r.itLeaf = r.itRuns = 0;
+    r.topHits[0] = r.topHits[1] = r.topHits[2] = 0;
+    r.cycInner = r.cycLeaf = r.cycRun = 0;
+    __shared__ uint32_t nodeBlkAll[kBlockWaves][2]; // per wave: next free slot and end of its block of node slots
+    volatile __attribute__((address_space(3))) uint32_t* nodeBlk = (volatile __attribute__((address_space(3))) uint32_t*)nodeBlkAll[threadIdx.x >> 6];
+    if (lane == 0)
+        nodeBlk[0] = nodeBlk[1] = 0u;
+    // the open hits of this lane's walk, by depth: the hit's node, how many of its children are done, its last child's node
+    __shared__ uint32_t frameNodeAll[kMaxDepth * kBlockThreads], frameDoneAll[kMaxDepth * kBlockThreads], frameLastAll[kMaxDepth * kBlockThreads];
+    uint32_t* frameNode = frameNodeAll + threadIdx.x;
+    uint32_t* frameDone = frameDoneAll + threadIdx.x;
+    uint32_t* frameLast = frameLastAll + threadIdx.x;
+    const uint32_t g = ft.glossySamples;
+
+    uint32_t item = 0, nrays = 0, made = 0;
+    int px = 0, py = 0;
+    uint32_t rayI = 0, sPix = 0, sLens = 0, sMain = 0, draws = 0;
+    f3 pof = mk3(0.0f);
+    int sp = 0;          // open hits; the ray in flight is a child of frame sp - 1 (a camera ray when sp == 0)
+    bool needRay = false; // the pixel's next camera ray is to be made
+    bool have = false, dead = false;
+    WaveQueue q;
+    q.start(total, wp.ownShare, 64u, 64u);
+
+    // node slots: every wave owns a block of consecutive slots and hands them out itself (see pathKernel)
+    auto allocNode = [&]() -> uint32_t {
+        const unsigned long long am = __ballot(true);
+        const uint32_t n = (uint32_t)__popcll(am), rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+        const uint32_t nodeCur = nodeBlk[0], nodeEnd = nodeBlk[1];
+        const uint32_t rem = nodeEnd - nodeCur;
+        uint32_t fresh = 0;
+        if (n > rem) {
+            const int leader = __builtin_ctzll(am);
+            if (lane == (uint32_t)leader)
+                fresh = atomicAdd(&ctr->nodes.v, nodeBlock);
+            fresh = __shfl(fresh, leader);
+        }
+        const uint32_t idx = rank < rem ? nodeCur + rank : fresh + (rank - rem);
+        if (rank == 0) {
+            nodeBlk[0] = n > rem ? fresh + (n - rem) : nodeCur + n;
+            if (n > rem)
+                nodeBlk[1] = fresh + nodeBlock;
+        }
+        return idx;
+    };
+    // the node just made becomes the next child of the innermost open hit
+    auto linkChild = [&](uint32_t idx) {
+        const uint32_t top = kBlockThreads * (uint32_t)(sp - 1);
+        const uint32_t last = frameLast[top];
+        if (last == (uint32_t)kChildNone)
+            wb.nodeB[frameNode[top]].childR = (int32_t)idx;
+        else
+            wb.nodeB[last].childP = (int32_t)idx;
+        frameLast[top] = idx;
+    };
+    // the next glossy ray of the innermost open hit (src/extra.cpp:333-362), rebuilt from the hit's record
+    auto spawnChild = [&]() {
+        const uint32_t n = frameNode[kBlockThreads * (uint32_t)(sp - 1)];
+        const float4* a = wb.nodeA + 4u * (size_t)n;
+        const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+        const f3 P = { a0.x, a0.y, a0.z }, N = { a0.w, a1.x, a1.y }, rd = { a1.z, a1.w, a2.x };
+        f3 o, R;
+        reflectionRay(P, rd, N, o, R);
+        f3 arbitrary = { 1.0f, 0.0f, 0.0f };
+        if (length(arbitrary - R) < 0.01f)
+            arbitrary = { 0.0f, 1.0f, 0.0f };
+        const f3 u = normalize(cross(arbitrary, R));
+        const f3 v = normalize(cross(R, u));
+        const float radius = ft.glossyExponent * a3.w / 64.0f;
+        const float sx = next1d(sMain);
+        const float sy = next1d(sMain);
+        draws += 2u;
+        const float rr = radius * sx;
+        const float theta = kTwoPi * sy;
+        const f3 sU = u * rr * cosLikeHost(theta);
+        const f3 sV = v * rr * sinLikeHost(theta);
+        const f3 dir = normalize(R + sU + sV);
+        tracer.launch(r, P + dir * 1.0e-5f, dir, kFltMax, K_RADIANCE);
+        nrays++;
+    };
+
+    for (;;) {
+        for (int round = 0; round < 2; round++) {
+            bool want = !have && !dead;
+            q.fetch(want, item, dead, &ctr->next, &ctr->dry[0], total, lane);
+            if (!have && !dead && !want) {
+                if (slotToPixel(fr, wp.slotBegin + item, px, py)) { // (padding pixels of partial edge tiles have no rays)
+                    const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
+                    sPix = seed;
+                    sLens = ft.lensMul * seed + ft.lensAdd;
+                    sMain = ft.mainMul * seed + ft.mainAdd;
+                    draws = 0;
+                    rayI = 0;
+                    sp = 0;
+                    needRay = true;
+                    have = true;
+                    r.active = false;
+                }
+            }
+            while (have && !r.active) {
+                if (needRay) {
+                    if (rayI >= wp.R) { // the pixel's tree is written down
+                        have = false;
+                        break;
+                    }
+                    f3 o, d;
+                    cameraRay<DOF>(cam, ft, fr, px, py, rayI, sPix, sLens, pof, o, d);
+                    tracer.launch(r, o, d, kFltMax, K_RADIANCE); // (counted with the batch's camera rays, below)
+                    needRay = false;
+                    sp = 0;
+                    continue; // a ray that misses the scene's box has finished already
+                }
+                tracer.settleTie(r);
+                if (sc.nSpheres)
+                    tracer.spheres(r);
+                const uint32_t path = item * wp.R + rayI;
+                bool spawned = false;
+                if (r.hitPrim == kHitNone) { // src/recursive.cpp:29-32
+                    if (sp == 0) {
+                        wb.pathHead[path] = kPathMiss;
+                        if (ft.envMap) {
+                            const f3 env = sampleEnvironmentMap(sc, ft, r.d);
+                            wb.pathEnv[3u * path + 0] = env.x;
+                            wb.pathEnv[3u * path + 1] = env.y;
+                            wb.pathEnv[3u * path + 2] = env.z;
+                        }
+                    } else if (ft.envMap) {
+                        // a child that left the scene with a colour of its own: a node without a hit, which carries the
+                        // colour (without an environment map such a child adds exactly zero and is left out)
+                        const f3 env = sampleEnvironmentMap(sc, ft, r.d);
+                        const uint32_t idx = allocNode();
+                        if (idx < wb.maxNodes) {
+                            NodeB nb {};
+                            nb.path = kDeadNode;
+                            nb.childR = nb.childP = kChildNone;
+                            nb.cvR[0] = env.x, nb.cvR[1] = env.y, nb.cvR[2] = env.z;
+                            wb.nodeB[idx] = nb;
+                            linkChild(idx);
+                        } else {
+                            atomicAdd(&ctr->overflow, 1ull);
+                        }
+                    }
+                } else {
+                    const HitCtx h = shadeHit(sc, ft, r);
+                    const uint32_t idx = allocNode();
+                    if (idx < wb.maxNodes) { // always: the pool holds the worst case of the batch
+                        made++;
+                        float4* a = wb.nodeA + 4u * (size_t)idx;
+                        a[0] = make_float4(h.P.x, h.P.y, h.P.z, h.N.x);
+                        a[1] = make_float4(h.N.y, h.N.z, r.d.x, r.d.y);
+                        a[2] = make_float4(r.d.z, h.kd.x, h.kd.y, h.kd.z);
+                        a[3] = make_float4(h.ks.x, h.ks.y, h.ks.z, h.shin);
+                        NodeB nb {};
+                        nb.path = path;
+                        nb.ordinal = draws; // where this hit's light samples draw (counted from the first such draw of the pixel)
+                        nb.depth = sp;
+                        nb.childR = nb.childP = kChildNone;
+                        nb.tr = h.tr;
+                        nb.mkd[0] = h.mkd.x, nb.mkd[1] = h.mkd.y, nb.mkd[2] = h.mkd.z;
+                        wb.nodeB[idx] = nb;
+                        if (sp == 0)
+                            wb.pathHead[path] = (int32_t)idx;
+                        else
+                            linkChild(idx);
+                        // computeLightContribution draws before the glossy rays do (src/recursive.cpp:36, :53)
+                        draws += wp.drawsPerHit;
+                        sMain = lcgSkip(sMain, wp.drawsPerHit);
+                        const bool reflective = !(h.ks.x == 0.0f && h.ks.y == 0.0f && h.ks.z == 0.0f);
+                        if (sp < ft.maxDepth && ft.reflections && reflective && (int)g > 0) {
+                            const uint32_t top = kBlockThreads * (uint32_t)sp;
+                            frameNode[top] = idx;
+                            frameDone[top] = 0u;
+                            frameLast[top] = (uint32_t)kChildNone;
+                            sp++;
+                            spawnChild();
+                            spawned = true;
+                        }
+                    } else {
+                        if (sp == 0)
+                            wb.pathHead[path] = kPathMiss;
+                        atomicAdd(&ctr->overflow, 1ull);
+                    }
+                }
+                if (!spawned) {
+                    // this ray's subtree is complete: its next sibling, or the next sibling of the nearest open hit that has one
+                    for (;;) {
+                        if (sp == 0) {
+                            rayI++;
+                            needRay = true;
+                            break;
+                        }
+                        const uint32_t top = kBlockThreads * (uint32_t)(sp - 1);
+                        const uint32_t done = frameDone[top] + 1u;
+                        frameDone[top] = done;
+                        if (done < g) {
+                            spawnChild();
+                            break;
+                        }
+                        sp--;
+                    }
+                }
+            }
+            if (__ballot(!have && !dead) == 0ull)
+                break;
+        }
+        if (__ballot(r.active && have) == 0ull) {
+            if (__ballot(!dead) == 0ull)
+                break;
+            continue;
+        }
+        tracer.run(r, q.exhausted ? (minActive & ~0xff) : minActive);
+    }
+
+    // the unused tail of the wave's last block: slots that hold no hit
+    for (uint32_t i = nodeBlk[0] + lane, e = nodeBlk[1]; i < e && i < wb.maxNodes; i += 64u)
+        wb.nodeB[i].path = kDeadNode;
+
+    const unsigned long long srays = ft.shadows ? waveSum(made) * wp.slots : 0ull;
+    const unsigned long long rs = waveSum(nrays), ni = waveSum(r.nInner), nt = waveSum(r.nTris);
+    __shared__ unsigned long long raySums[kBlockWaves][2];
+    if (lane == 0)
+        raySums[threadIdx.x >> 6][0] = rs + srays, raySums[threadIdx.x >> 6][1] = srays;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // glossy rays counted here; every camera ray of a real pixel is one intersect call
+        unsigned long long all = blockIdx.x == 0 ? (unsigned long long)wp.validPaths : 0ull, shadow = 0ull;
+        for (uint32_t w = 0; w < kBlockWaves; w++)
+            all += raySums[w][0], shadow += raySums[w][1];
+        if (all)
+            atomicAdd(&ctr->rays, all);
+        if (shadow)
+            atomicAdd(&ctr->sRays, shadow);
+    }
+    if (STATS && lane == 0) {
+        atomicAdd(&ctr->inner, ni);
+        atomicAdd(&ctr->tris, nt);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // 2. per pixel: how many hits precede each of its paths
 // ---------------------------------------------------------------------------
 __global__ void prefixKernel(const DevFrame fr, const WfParams wp, const WfBuffers wb)
@@ -613,8 +884,10 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
                 int px, py;
                 slotToPixel(fr, wp.slotBegin + fastDiv(path, wp.divR), px, py);
                 const uint32_t seed = (uint32_t)(fr.height * px + py);
-                const uint32_t hitOrdinal = wb.pathBase[path] + ordinal;
-                uint32_t s = lcgSkip(seed, wp.mainStart + wp.drawsPerHit * hitOrdinal + drawPrefix + slot * perSample);
+                // where the hit's light-sample draws begin: with glossy reflections the tree kernel knew and
+                // wrote it down; otherwise it follows from the number of hits before this one in its pixel
+                const uint32_t hitDraws = wp.absDraws ? ordinal : wp.drawsPerHit * (wb.pathBase[path] + ordinal);
+                uint32_t s = lcgSkip(seed, wp.mainStart + hitDraws + drawPrefix + slot * perSample);
                 f3 pos, col;
                 if (light.type == 0) {
                     pos = ld3(light.v + 0);
@@ -1054,10 +1327,72 @@ __device__ __forceinline__ f3 pathValueTree(const DevScene& sc, const DevFeat& f
     }
 }
 
+// With glossy reflections: a hit's own light plus the mean of its glossy children's values times ks
+// (src/extra.cpp:364-367), children in the order they were traced (first child, then next siblings).  A
+// node without a hit is a child that left the scene and carries the environment's colour.
+__device__ __forceinline__ f3 pathValueGlossy(const DevScene& sc, const DevFeat& ft, const WfParams& wp, const WfBuffers& wb, uint32_t path)
+{
+    const int32_t head = wb.pathHead[path];
+    if (head == kPathMiss)
+        return ft.envMap ? ld3(wb.pathEnv + 3u * path) : mk3(0.0f);
+    int32_t nodeAt[kMaxDepth + 1], child[kMaxDepth + 1]; // child: the child under way, or kChildNone before the first
+    f3 Lo[kMaxDepth + 1], acc[kMaxDepth + 1];
+    int sp = 0;
+    nodeAt[0] = head;
+    bool entering = true;
+    f3 ret = mk3(0.0f);
+    for (;;) {
+        const uint32_t n = (uint32_t)nodeAt[sp];
+        int32_t next;
+        if (entering) {
+            const NodeB& nb = wb.nodeB[n];
+            bool leaf = true;
+            if (nb.path == kDeadNode) {
+                ret = ld3(nb.cvR);
+            } else {
+                Lo[sp] = nodeLo(sc, ft, wb, n, wp.slots);
+                const float4 a3 = wb.nodeA[4u * (size_t)n + 3];
+                const bool reflective = !(a3.x == 0.0f && a3.y == 0.0f && a3.z == 0.0f);
+                if (nb.depth < ft.maxDepth && ft.reflections && reflective) {
+                    acc[sp] = mk3(0.0f);
+                    leaf = false;
+                } else {
+                    ret = Lo[sp];
+                }
+            }
+            if (leaf) {
+                if (sp == 0)
+                    return ret;
+                sp--;
+                entering = false;
+                continue;
+            }
+            next = nb.childR;
+        } else { // a child's value has come back
+            acc[sp] = acc[sp] + ret;
+            next = wb.nodeB[child[sp]].childP;
+        }
+        if (next >= 0 && sp < kMaxDepth) {
+            child[sp] = next;
+            sp++;
+            nodeAt[sp] = next;
+            entering = true;
+            continue;
+        }
+        const float4 a3 = wb.nodeA[4u * (size_t)n + 3];
+        ret = Lo[sp] + (acc[sp] / (float)(int)ft.glossySamples) * mk3(a3.x, a3.y, a3.z);
+        if (sp == 0)
+            return ret;
+        sp--;
+        entering = false;
+    }
+}
+
 // One lane per camera ray evaluates its chain (the chains of a pixel sit all over the node
 // pool, so their latencies overlap instead of queueing up in one lane); the first lane of
 // each pixel then adds the pixel's values in ray order, exactly as renderRays does.
-template <bool TRANSP>
+// MODE 0: chains of mirror hits, 1: trees with pass-through children (transparency), 2: trees of glossy children
+template <int MODE>
 __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp,
     const WfBuffers wb, float* __restrict__ out)
 {
@@ -1076,7 +1411,8 @@ __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const De
         const uint32_t i = base + j;
         f3 v = mk3(0.0f);
         if (sees && i < wp.R)
-            v = TRANSP ? pathValueTree(sc, ft, wp, wb, s * wp.R + i) : pathValue(sc, ft, wp, wb, s * wp.R + i);
+            v = MODE == 2 ? pathValueGlossy(sc, ft, wp, wb, s * wp.R + i)
+                : (MODE == 1 ? pathValueTree(sc, ft, wp, wb, s * wp.R + i) : pathValue(sc, ft, wp, wb, s * wp.R + i));
         vals[3u * threadIdx.x + 0] = v.x;
         vals[3u * threadIdx.x + 1] = v.y;
         vals[3u * threadIdx.x + 2] = v.z;
@@ -1172,9 +1508,45 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, in
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
     const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
     if (transp)
-        hipLaunchKernelGGL(combineKernel<true>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
+        hipLaunchKernelGGL(combineKernel<1>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
     else
-        hipLaunchKernelGGL(combineKernel<false>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
+        hipLaunchKernelGGL(combineKernel<0>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
+    return hipGetLastError();
+}
+
+typedef void (*GlossyFn)(const DevScene, const DevCamera, const DevFeat, const DevFrame, const WfParams, const WfBuffers, DevCounters*, int);
+static GlossyFn glossyVariant(bool dof, bool stats)
+{
+    if (dof)
+        return stats ? glossyTreeKernel<true, true> : glossyTreeKernel<true, false>;
+    return stats ? glossyTreeKernel<false, true> : glossyTreeKernel<false, false>;
+}
+
+hipError_t glossyOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* treeBlocks)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(treeBlocks, glossyVariant(dof, stats), blockThreads, ldsBytes);
+}
+
+// The frame with glossy reflections: the tree kernel writes every pixel's hits down, the light samples of all
+// hits are generated, traced and shaded as for mirror reflections, the combine folds the trees.
+hipError_t launchWavefrontGlossy(bool dof, bool stats, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
+    const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp, const WfBuffers& wb, DevCounters* ctr,
+    float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU)
+{
+    hipLaunchKernelGGL(glossyVariant(dof, stats), dim3(treeBlocks), dim3(blockThreads), ldsBytes, stream, sc, cam, ft, fr, wp, wb, ctr, minActive);
+    if (marks)
+        (void)hipEventRecord(marks[0], stream);
+    hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * RT_GEN_BLOCKS), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr, sc.lights);
+    if (marks)
+        (void)hipEventRecord(marks[1], stream);
+    hipLaunchKernelGGL(shadowVariant(stats, false), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
+    if (marks)
+        (void)hipEventRecord(marks[2], stream);
+    if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr)
+        hipLaunchKernelGGL(shadowRedoKernel, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr);
+    const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
+    const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
+    hipLaunchKernelGGL(combineKernel<2>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
     return hipGetLastError();
 }
 

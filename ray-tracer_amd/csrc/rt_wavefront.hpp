@@ -12,6 +12,9 @@ namespace rt {
 struct NodeB {
     uint32_t path;    // path index inside the batch
     uint32_t ordinal; // position of the hit among its camera ray's hits in the order renderRay visits them
+                      // (glossy reflections, WfParams::absDraws: the position of the hit's light-sample draws in its pixel's
+                      // stream, counted from the first such draw; childR = first glossy child, childP = next sibling;
+                      // path == kDeadNode with cvR set: a child that left the scene, carrying the environment's colour)
     int32_t depth;    // rayDepth of the ray that made the hit
     int32_t childR;   // mirror child: kChildNone, kChildMiss (its value in cvR), or node index
     int32_t childP;   // pass-through child, likewise (cvP)
@@ -58,11 +61,17 @@ struct WfParams {
     uint32_t nodeBlockMax;   // node slots a wavefront reserves at a time, at most (64 <= power of two <= kNodeBlock)
     uint32_t ownShare;   // sixteenths of a queue that its waves split up by position instead of fetching
     uint32_t validPaths; // camera rays of the batch's real (non-padding) pixels
+    uint32_t absDraws;   // 1: NodeB::ordinal is the position of the hit's light-sample draws itself (glossy reflections)
 };
 
 hipError_t wavefrontOccupancy(bool stats, bool transp, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
 hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
     const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
+
+hipError_t glossyOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* treeBlocks);
+hipError_t launchWavefrontGlossy(bool dof, bool stats, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
+    const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp, const WfBuffers& wb, DevCounters* ctr,
+    float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
 
 } // namespace rt

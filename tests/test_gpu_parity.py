@@ -145,8 +145,8 @@ def test_three_kinds_of_light_odd_counts(ctx):
 def test_jittered_sampling_and_glossy_reflections(ctx):
     """generatePixelRaysStratified (src/render.cpp:103-131) on the queue-based path, and glossy
     reflections (src/extra.cpp:329-368), whose sample directions consume draws in the recursion's
-    own order and therefore run on the per-pixel kernel, also combined with transparency and
-    depth of field."""
+    own order (the queue-based renderer's tree kernel; combined with transparency, the per-pixel
+    kernel), also with depth of field."""
     import copy
     scn = copy.deepcopy(common.scene("CornellBox"))
     scn.lights = [sio.cornell_parallelogram_light()]
@@ -171,6 +171,69 @@ def test_jittered_sampling_and_glossy_reflections(ctx):
         print(f"{name}: rays {st_g['rays']} (oracle {st_o['rays']}) maxabs {maxabs:.3g}")
         assert st_g["rays"] == st_o["rays"] and ref.any()
         assert maxabs <= 2e-5 and rmse <= 2e-6
+
+
+def test_glossy_reflections_on_the_queue_based_renderer():
+    """Glossy reflections without transparency run on the queue-based renderer: a tree kernel walks every pixel's
+    camera and glossy rays in the recursion's order (the directions are drawn, src/extra.cpp:348-362) and writes the
+    hits down, the light samples of all hits go through the same kernels as for mirror reflections, and the combine
+    folds the trees.  Against the oracle, and bit for bit against the per-pixel kernel: one to four glossy samples,
+    depth caps one to three, several camera rays per pixel, a lens, an environment map (children that leave the
+    scene carry a colour), all three kinds of light, pixel batches (a small workspace), shards."""
+    import copy
+    scn = copy.deepcopy(common.scene("CornellBox", env_map=True))
+    scn.lights = [sio.cornell_parallelogram_light(), sio.point_light((0.2, 0.3, 0.4), (0.6, 0.5, 0.4)),
+                  sio.segment_light((-0.3, 0.4, -0.2), (0.3, 0.4, 0.2), (1, 0, 0), (0, 0, 1))]
+    osc = orc.OracleScene(scn)
+    w, h = 56, 40
+    cam = sio.default_camera(w, h)
+    cases = [
+        dict(numGlossySamples=1, glossyExponent=0.5, maxRayDepth=3, numShadowSamples=1),
+        dict(numGlossySamples=2, glossyExponent=1.0, maxRayDepth=2, numShadowSamples=2, enableEnvironmentMap=1),
+        dict(numGlossySamples=3, glossyExponent=0.25, maxRayDepth=2, numShadowSamples=1, numPixelSamples=4, enableJitteredSampling=1),
+        dict(numGlossySamples=4, glossyExponent=0.7, maxRayDepth=1, numShadowSamples=3, numPixelSamples=3, enableEnvironmentMap=1,
+             enableDepthOfField=1, numDepthOfFieldSamples=2, depthOfFieldDistance=2.5),
+        dict(numGlossySamples=2, glossyExponent=0.5, maxRayDepth=3, numShadowSamples=0),
+        dict(numGlossySamples=2, glossyExponent=0.5, maxRayDepth=0, numShadowSamples=1),
+    ]
+    for k, kw in enumerate(cases):
+        f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, enableGlossyReflection=1,
+                            enableNormalInterp=1, **kw)
+        ref, st_o = osc.render(f, cam, w, h)
+        images = {}
+        for name, opts in (("queues", dict(per_pixel=0)), ("queues, small workspace", dict(per_pixel=0, workspace_bytes=3 << 20)),
+                           ("per pixel", dict(per_pixel=1))):
+            c = _ctx_with(**opts)
+            c.upload_scene(scn)
+            c.set_features(f)
+            img, st = c.render(cam, w, h)
+            c.close()
+            assert st["rays"] == st_o["rays"], (k, name, st["rays"], st_o["rays"])
+            images[name] = img
+        finite = np.isfinite(ref)
+        maxabs = float(np.abs(images["queues"][finite].astype(np.float64) - ref[finite].astype(np.float64)).max())
+        # (no light samples at all: 0 * (1 / 0), every lit pixel is not a number on both sides)
+        assert (ref[finite].any() or kw["numShadowSamples"] == 0) and maxabs <= 2e-5, (k, maxabs)
+        assert np.array_equal(np.isfinite(images["queues"]), finite), k
+        for name in ("queues, small workspace", "per pixel"):
+            assert np.array_equal(images["queues"].view(np.uint32), images[name].view(np.uint32)), (k, name)
+    # shards of the frame, packed, against the per-pixel kernel's
+    f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, enableGlossyReflection=1,
+                        numGlossySamples=2, glossyExponent=0.5, maxRayDepth=2, numShadowSamples=2, numPixelSamples=2)
+    import torch
+    for shard in range(3):
+        outs = []
+        for opts in (dict(per_pixel=0), dict(per_pixel=1)):
+            c = _ctx_with(**opts)
+            c.upload_scene(scn)
+            c.set_features(f)
+            n = capi.shard_floats(w, h, shard, 3)
+            buf = torch.zeros(n, dtype=torch.float32, device="cuda")
+            c.render_device(cam, w, h, buf.data_ptr(), n, shard, 3, 0)
+            c.sync(0)
+            outs.append(buf.cpu().numpy())
+            c.close()
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)) and outs[0].any(), shard
 
 
 def test_shading_models_and_texture_filters(ctx):

@@ -1,7 +1,6 @@
 """rt_render_device_noalloc: the entry point that allocates nothing, through the C ABI, against
 rt_render_device on the same inputs -- the same bits and the same ray counts, on calls in a row of
-which the later ones are smaller than the first (the scratch keeps the earlier call's contents); and the same
-call recorded into a HIP graph and replayed."""
+which the later ones are smaller than the first (the scratch keeps the earlier call's contents)."""
 import importlib
 
 import numpy as np
@@ -113,59 +112,4 @@ def test_no_alloc_render_refuses_what_does_not_fit():
     with pytest.raises(capi.RtError) as e:
         c.render_device_noalloc(sio.default_camera(128, 128), 128, 128, out.data_ptr(), out.numel())
     assert e.value.code == -1
-    c.close()
-
-
-@pytest.mark.parametrize("dragon", [False, True])
-def test_no_alloc_render_replays_from_a_graph(dragon):
-    """Recorded into a HIP graph by stream capture and replayed: the replays leave the bits of the direct call.
-    (What made an earlier attempt fault on replay was the copy of the lights from the caller's pageable memory that
-    a render call used to enqueue; lights are now written to a device slot when they are set.)  Two frames: the
-    Cornell box, and the dragon with an area light, whose working set takes several pixel batches of the scratch."""
-    import torch
-    if dragon:
-        scn = _dragon()
-        f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, numPixelSamples=16,
-                            numShadowSamples=4, maxRayDepth=4)
-        w, h = 192, 108
-        cam = sio.default_camera(w, h, distance=1.6)
-    else:
-        scn = common.scene("CornellBox")
-        f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, numPixelSamples=4, maxRayDepth=3)
-        w, h = 96, 64
-        cam = sio.default_camera(w, h)
-    c = capi.Context(0)
-    c.upload_scene(scn)
-    c.set_features(f)
-    n = w * h * 3
-    want = torch.zeros(n, dtype=torch.float32, device="cuda")
-    got = torch.zeros(n, dtype=torch.float32, device="cuda")
-    s = torch.cuda.Stream()
-    # directly, twice (the first call of a context sizes its plan)
-    for _ in range(2):
-        c.render_device_noalloc(cam, w, h, want.data_ptr(), n, 0, 1, s.cuda_stream)
-    st = c.sync(s.cuda_stream)
-    assert st["rays"] > w * h * 4 and bool(want.any())
-    # recorded
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=s):
-        c.render_device_noalloc(cam, w, h, got.data_ptr(), n, 0, 1, torch.cuda.current_stream().cuda_stream)
-    for k in range(2):
-        got.zero_()
-        torch.cuda.synchronize()
-        g.replay()
-        torch.cuda.synchronize()
-        assert np.array_equal(want.cpu().numpy().view(np.uint32), got.cpu().numpy().view(np.uint32)), k
-    # the lights as they were when the graph was recorded stay the replay's lights; a frame made directly after new
-    # lights were set has the new ones
-    c.set_lights([sio.point_light((0.3, 0.4, 0.2), (0.5, 1.0, 0.25))])
-    other = torch.zeros(n, dtype=torch.float32, device="cuda")
-    c.render_device_noalloc(cam, w, h, other.data_ptr(), n, 0, 1, s.cuda_stream)
-    c.sync(s.cuda_stream)
-    assert not np.array_equal(want.cpu().numpy().view(np.uint32), other.cpu().numpy().view(np.uint32))
-    got.zero_()
-    g.replay()
-    torch.cuda.synchronize()
-    assert np.array_equal(want.cpu().numpy().view(np.uint32), got.cpu().numpy().view(np.uint32))
-    del g
     c.close()
