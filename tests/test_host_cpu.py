@@ -210,3 +210,20 @@ def test_bench_refuses_a_launcher_of_another_size():
     out = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
                          env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "4" in out.stderr
+
+
+def test_stored_counters_and_probe_peaks_belong_to_the_kernels_as_they_are():
+    """bench.py's roofline takes hardware counters from a committed rocprofv3 pass (it cannot collect them inside its
+    own process) and the vector ALU's peak from a committed probe run.  The counters only count if the pass ran on the
+    kernel sources as they are now: a pass on other sources must yield no fraction at all, and the committed one must
+    be current."""
+    import bench
+    ctrs, src, fresh = bench.stored_counters("dragon", "shadowTraceKernel", 1, 1920, 1080)
+    assert ctrs and fresh, src
+    assert ctrs["SQ_INSTS_VALU"] > 1e9 and ctrs["TCP_TOTAL_CACHE_ACCESSES_sum"] > 1e9
+    peak = bench.valu_probe_peak()
+    assert peak and peak["waves_per_simd"] == 6 and 300.0 < peak["chip_G_wave_instructions_per_s"] < 1300.0
+    # no pass for another resolution, camera or world size
+    assert bench.stored_counters("dragon", "shadowTraceKernel", 1, 960, 540)[0] is None
+    assert bench.stored_counters("dragon", "shadowTraceKernel", 2, 1920, 1080)[0] is None
+    assert bench.stored_counters("dragon", "shadowTraceKernel", 1, 1920, 1080, 1.6)[0] is None
