@@ -1118,3 +1118,38 @@ def test_full_size_frame_properties():
     assert np.isfinite(a).all() and float(a.max()) <= 1.0 + 1e-6 and float(a.sum()) > 100.0
     # a 1/16-size crop of the same view against the oracle would need another camera; the small
     # configurations above pin the oracle, this one pins the size
+
+
+def test_largest_configuration_at_its_full_size_properties():
+    """BASELINE's largest configuration at its real size: 3840x2160, 64 pixel samples x 5 lens samples, area
+    light x 4, transparency 0.6, depth cap 4 -- 47 G rays, a few hours of the CPU oracle, so no oracle here
+    (its features are compared with the oracle at 240x136 in test_largest_configurations_features_match_the_oracle).
+    What can be asked of the full frame: rendered whole and rendered as two shards of interleaved tiles put back
+    together it is the same frame bit for bit, the shards' rays add up to the whole frame's, and that number is the
+    one every build of this library has counted for this frame."""
+    import bench
+    import torch
+    scn, f, w, h, _ = bench.build_workload("dragon4k")
+    cam = sio.default_camera(w, h)
+    c = _ctx_with()
+    c.upload_scene(scn)
+    c.set_features(f)
+    whole = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    c.render_device(cam, w, h, whole.data_ptr(), whole.numel(), 0, 1, 0)
+    st = c.sync(0)
+    assert st["rays"] == 47_093_965_626
+    stride = capi.shard_floats(w, h, 0, 2)
+    packed = torch.zeros((2, stride), dtype=torch.float32, device="cuda")
+    rays = 0
+    for shard in range(2):
+        c.render_device(cam, w, h, packed[shard].data_ptr(), stride, shard, 2, 0)
+        rays += c.sync(0)["rays"]
+    assert rays == st["rays"]
+    frame = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    c.deinterleave(packed.data_ptr(), w, h, 2, frame.data_ptr(), 0)
+    c.postprocess(frame.data_ptr(), w, h, 0)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(whole.view(torch.int32), frame.view(torch.int32)))
+    a = whole.cpu().numpy()
+    assert np.isfinite(a).all() and float(a.max()) <= 1.0 + 1e-6 and float(a.sum()) > 1000.0
+    c.close()
