@@ -257,9 +257,9 @@ static int lightsUsedBy(rt_ctx* ctx, hipStream_t stream)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream != nullptr && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return RT_OK;
-    hipEvent_t& ev = ctx->lightSlotUsed[ctx->lightSlot];
+    hipEvent_t ev = ctx->lightSlotUsed[ctx->lightSlot]; // (made by rt_lights_set: a render call creates nothing)
     if (!ev)
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        return RT_OK;
     HIP_TRY(ctx, hipEventRecord(ev, stream));
     ctx->lightSlotPending[ctx->lightSlot] = true;
     return RT_OK;
@@ -1138,8 +1138,11 @@ try {
         if (lights[i].type < 0 || lights[i].type > 2)
             return fail(ctx, RT_ERR_INVALID, "rt_lights_set: light %u has type %d", i, lights[i].type);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->copyStream)
+    if (!ctx->copyStream) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking));
+        for (hipEvent_t& e : ctx->lightSlotUsed)
+            HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     if (n > ctx->lightCap || !ctx->dLights) {
         HIP_TRY(ctx, hipDeviceSynchronize());
         if (ctx->dLights)
