@@ -711,7 +711,7 @@ __global__ void evalKernel(const DevScene sc, const DevCamera cam, const DevFeat
 } // namespace rt
 
 // ----------------------------------------------------------------------------
-// Launchers used by the C ABI (rt_capi.cpp)
+// Launchers used by the C ABI (rt_capi.cpp, rt_capi_render.cpp)
 // ----------------------------------------------------------------------------
 namespace rt {
 

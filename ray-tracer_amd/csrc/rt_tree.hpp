@@ -1,6 +1,6 @@
 // rt_tree.hpp -- the library's own traversal hierarchy: the items it is built over, the grid its boxes are
 // quantised on, and the device-side builder's interface (rt_tree.hip).  The host-side builder (full-sweep
-// surface-area heuristic) lives in rt_capi.cpp.
+// surface-area heuristic) lives in rt_capi_build.cpp.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -1,5 +1,5 @@
 // rt_wavefront.hpp -- buffers and launch interface of the queue-based renderer
-// (rt_wavefront.hip), shared with the host side (rt_capi.cpp).
+// (rt_wavefront.hip), shared with the host side (rt_capi_render.cpp).
 #pragma once
 
 #include "rt_device.hpp"
