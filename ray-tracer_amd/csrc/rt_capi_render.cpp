@@ -161,6 +161,14 @@ size_t traversalLds(const rt_ctx* ctx)
 
 namespace {
 
+// Motion blur on the queue-based renderer: every (pixel, time sample) pair takes a pixel's place in the queues
+// (rt_wavefront.hpp).  Together with transparency or glossy reflections, or without a single time sample (0 / 0 in every
+// pixel, src/extra.cpp:208), the per-pixel kernel renders it.
+static bool motionOnQueues(const rt_features& F)
+{
+    return motionBlurOn(F) && F.motionBlurSamples > 0 && !F.enableTransparency && !(F.enableGlossyReflection && F.enableReflections);
+}
+
 static int perPixelVariant(const rt_features& F, bool collect)
 {
     int variant = 0;
@@ -195,7 +203,7 @@ int warmOccupancy(rt_ctx* ctx)
     o.transp = F.enableTransparency != 0;
     o.variant = perPixelVariant(F, false);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, wavefrontOccupancy(false, o.transp != 0, kBlockThreads, o.lds, &o.path, &o.shadow));
+    HIP_TRY(ctx, wavefrontOccupancy(false, o.transp != 0, motionOnQueues(F), kBlockThreads, o.lds, &o.path, &o.shadow));
     HIP_TRY(ctx, renderOccupancy(o.variant, kBlockThreads, o.lds, &o.render));
     o.valid = true;
     ctx->occ = o;
@@ -247,7 +255,8 @@ static int traceKnobs(int minActive, int a, int b)
 // framework/src/trackball.cpp:101-110), a pixel wider on every side.  Only such pixels can make hits, so
 // only they need room in the pools of hits and light samples.  Every real pixel counts when the bound
 // does not apply: a corner beside or behind the camera, rays that start on a lens instead of the camera's
-// position (depth of field), spheres in the scene or the acceleration structure off (every ray is traced).
+// position (depth of field), a scene that moves (motion blur), spheres in the scene or the acceleration
+// structure off (every ray is traced).
 static void candidatePixelsPerTile(const rt_ctx* ctx, const rt_camera& camera, const DevFrame& fr, int width, int height,
     std::vector<uint16_t>& out, std::vector<uint32_t>& validBefore, int rect[4])
 {
@@ -256,7 +265,7 @@ static void candidatePixelsPerTile(const rt_ctx* ctx, const rt_camera& camera, c
     validBefore.assign(nTiles + 1, 0u);
     const rt_features& F = ctx->features;
     const DevScene& sc = ctx->scene;
-    bool bounded = F.enableAccelStructure && !F.enableDepthOfField && sc.nSpheres == 0 && sc.nPrims != 0;
+    bool bounded = F.enableAccelStructure && !F.enableDepthOfField && !motionBlurOn(F) && sc.nSpheres == 0 && sc.nPrims != 0;
     int x0 = 0, x1 = width - 1, y0 = 0, y1 = height - 1; // inclusive pixel rectangle
     if (bounded) {
         const DevCamera cam = makeCamera(camera);
@@ -359,7 +368,8 @@ static int launchPerPixel(rt_ctx* ctx, const DevCamera& cam, const DevFeat& ft, 
 struct QueueFrame {
     WfParams wp {};
     uint32_t slots = 0;                   // light samples per hit
-    bool dof = false, transp = false, glossy = false, envMap = false;
+    bool dof = false, transp = false, glossy = false, motion = false, envMap = false;
+    uint32_t raysPerSlot = 0;             // camera rays of a pixel slot: R, with motion blur times its time samples
     int pathBlocks = 0, shadowBlocks = 0; // blocks of the path (or glossy tree) kernel and of the shadow-ray kernels
     uint64_t perNodeBytes = 0;            // a hit with its light samples
     uint64_t nodeSlack = 0;               // node slots the path kernel's wavefronts may leave unused at the ends of their blocks
@@ -370,12 +380,13 @@ struct QueueFrame {
     size_t workspaceCap = 0;              // bytes the batches' buffers may take
 };
 
-static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const Arena* arena, size_t lds, bool glossyWf, bool collect,
-    bool occReady, QueueFrame& q)
+static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const Arena* arena, size_t lds, bool glossyWf, bool motionWf,
+    bool collect, bool occReady, QueueFrame& q)
 {
     const rt_features& F = ctx->features;
     WfParams& wp = q.wp;
     wp.R = ft.raysPerPixel;
+    const uint32_t timeSamples = motionWf ? static_cast<uint32_t>(F.motionBlurSamples) : 1u;
     uint32_t slots = 0, drawsPerHit = 0;
     for (const rt_light& l : ctx->hostLights) {
         slots += (l.type == 0) ? 1u : F.numShadowSamples;
@@ -394,8 +405,10 @@ static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const 
     wp.nodeBlockFixed = ctx->nodeBlockFixed ? 1u : 0u;
     wp.ownShare = ctx->ownShare;
     wp.absDraws = glossyWf ? 1u : 0u;
-    if (wp.R == 0 || wp.R > 65535u)
-        return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel", wp.R);
+    if (wp.R == 0 || wp.R > 65535u || static_cast<uint64_t>(wp.R) * timeSamples > 0xffffffull)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u camera rays per pixel (times %u time samples)", wp.R, timeSamples);
+    q.raysPerSlot = wp.R * timeSamples;
+    q.motion = motionWf;
     q.dof = F.enableDepthOfField != 0;
     q.transp = F.enableTransparency != 0;
     q.glossy = glossyWf;
@@ -405,7 +418,7 @@ static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const 
     if (occReady)
         pathPerCU = ctx->occ.path, shadowPerCU = ctx->occ.shadow;
     else
-        HIP_TRY(ctx, wavefrontOccupancy(collect, q.transp, kBlockThreads, lds, &pathPerCU, &shadowPerCU));
+        HIP_TRY(ctx, wavefrontOccupancy(collect, q.transp, motionWf, kBlockThreads, lds, &pathPerCU, &shadowPerCU));
     if (glossyWf) // (the tree kernel stands in the path kernel's place; asking is no allocation)
         HIP_TRY(ctx, glossyOccupancy(q.dof, collect, kBlockThreads, lds, &pathPerCU));
     if (pathPerCU < 1 || shadowPerCU < 1)
@@ -423,7 +436,7 @@ static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const 
         // means emptier ones that hold their slots until the last chain is done: a block per CU
         // for every 32 K camera rays per CU, at least one (measured: eighth to half of the headline
         // frame 4-5 % faster with frames in flight, 6 % alone; the whole frame keeps what fits).
-        const uint64_t perCU = (static_cast<uint64_t>(fr.nWork) * wp.R + static_cast<uint64_t>(ctx->numCU) * 32768 - 1)
+        const uint64_t perCU = (static_cast<uint64_t>(fr.nWork) * q.raysPerSlot + static_cast<uint64_t>(ctx->numCU) * 32768 - 1)
             / (static_cast<uint64_t>(ctx->numCU) * 32768);
         pathPerCU = static_cast<int>(std::min<uint64_t>(pathPerCU, std::max<uint64_t>(1, perCU)));
     }
@@ -478,7 +491,7 @@ static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const 
         nodesPerPath = (2ull << F.maxRayDepth) - 1;
     else if (mirrors || passes)
         nodesPerPath = static_cast<uint64_t>(F.maxRayDepth) + 1;
-    q.nodesPerPixel = static_cast<uint64_t>(wp.R) * nodesPerPath;
+    q.nodesPerPixel = static_cast<uint64_t>(q.raysPerSlot) * nodesPerPath;
     // what does not shrink with the batch: the unused ends of the node blocks, the buffers' alignment
     q.fixedBytes = q.nodeSlack * q.perNodeBytes + 16 * 256;
     // item index (node * slots + slot) in 32 bits, with room for the queue head to run past the end
@@ -488,8 +501,8 @@ static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const 
         return fail(ctx, RT_ERR_UNSUPPORTED, "render: %u light samples per hit exceed the supported count", slots);
     // per pixel slot: head, count, prefix (and environment colour) of each of its camera rays; per candidate
     // pixel: its queued camera rays and the worst case of its hits with their light samples
-    q.perSlot = static_cast<uint64_t>(wp.R) * (4 + 1 + 4 + (q.envMap ? 12 : 0));
-    q.perCand = static_cast<uint64_t>(wp.R) * 32 + q.nodesPerPixel * q.perNodeBytes;
+    q.perSlot = static_cast<uint64_t>(q.raysPerSlot) * (4 + 1 + 4 + (q.envMap ? 12 : 0));
+    q.perCand = static_cast<uint64_t>(q.raysPerSlot) * 32 + q.nodesPerPixel * q.perNodeBytes;
     return RT_OK;
 }
 
@@ -502,7 +515,7 @@ static void candidateTiles(rt_ctx* ctx, const rt_camera& camera, DevFrame& fr, i
     const rt_features& F = ctx->features;
     std::vector<uint8_t> key;
     keyAdd(key, camera), keyAdd(key, width), keyAdd(key, height), keyAdd(key, fr.shard), keyAdd(key, fr.nShard);
-    keyAdd(key, ctx->generation), keyAdd(key, F.enableAccelStructure), keyAdd(key, F.enableDepthOfField);
+    keyAdd(key, ctx->generation), keyAdd(key, F.enableAccelStructure), keyAdd(key, F.enableDepthOfField), keyAdd(key, F.enableMotionBlur);
     if (key != fp.tilesKey) {
         candidatePixelsPerTile(ctx, camera, fr, width, height, fp.tileCand, fp.validBefore, fp.rect);
         fp.tilesKey.swap(key);
@@ -517,7 +530,7 @@ static bool planBatches(rt_ctx::FramePlan& fp, const QueueFrame& q, uint32_t nTi
 {
     typedef rt_ctx::Batch Batch;
     std::vector<uint8_t> key;
-    keyAdd(key, cap), keyAdd(key, fixed), keyAdd(key, q.perSlot), keyAdd(key, q.perCand), keyAdd(key, q.wp.R), keyAdd(key, q.nodesPerPixel);
+    keyAdd(key, cap), keyAdd(key, fixed), keyAdd(key, q.perSlot), keyAdd(key, q.perCand), keyAdd(key, q.raysPerSlot), keyAdd(key, q.nodesPerPixel);
     keyAdd(key, q.nodeSlack), keyAdd(key, q.nodeCap);
     if (key == fp.planKey && !fp.batches.empty())
         return true; // the same frame under the same limits as last time
@@ -528,7 +541,7 @@ static bool planBatches(rt_ctx::FramePlan& fp, const QueueFrame& q, uint32_t nTi
     Batch cur { 0u, 0u, 0ull };
     for (uint32_t t = 0; t < nTiles; t++) {
         const uint64_t tiles = cur.tiles + 1ull, cand = cur.cand + fp.tileCand[t];
-        const bool fits = tiles * 64 * q.perSlot + cand * q.perCand <= room && tiles * 64 * q.wp.R <= 0x7fffffffull // path index in 31 bits
+        const bool fits = tiles * 64 * q.perSlot + cand * q.perCand <= room && tiles * 64 * q.raysPerSlot <= 0x7fffffffull // path index in 31 bits
             && cand * q.nodesPerPixel + q.nodeSlack <= q.nodeCap;
         if (!fits) {
             if (cur.tiles == 0)
@@ -553,7 +566,7 @@ constexpr int kQueueBuffers = 10;
 // rounded up to the 256 B it is aligned to.
 static size_t bufferSizes(const rt_ctx::FramePlan& fp, const QueueFrame& q, size_t want[kQueueBuffers], uint64_t& maxNodes)
 {
-    const uint64_t paths = fp.maxTiles * 64 * q.wp.R, queued = std::max<uint64_t>(1, fp.maxCand * q.wp.R);
+    const uint64_t paths = fp.maxTiles * 64 * q.raysPerSlot, queued = std::max<uint64_t>(1, fp.maxCand * q.raysPerSlot);
     maxNodes = fp.maxCand * q.nodesPerPixel + q.nodeSlack;
     const size_t items = static_cast<size_t>(maxNodes) * std::max(1u, q.slots);
     const size_t w[kQueueBuffers] = { static_cast<size_t>(paths) * 4, static_cast<size_t>(paths), static_cast<size_t>(paths) * 4,
@@ -658,7 +671,7 @@ static int launchBatches(rt_ctx* ctx, QueueFrame& q, const WfBuffers& wb, const 
                 offsetof(DevCounters, loopIters) - offsetof(DevCounters, next), stream));
         // real pixels of the batch's tiles (edge tiles are padded to 8x8 slots)
         const uint64_t validPixels = fp.validBefore[bt.firstTile + bt.tiles] - fp.validBefore[bt.firstTile];
-        wp.validPaths = static_cast<uint32_t>(validPixels * wp.R);
+        wp.validPaths = static_cast<uint32_t>(validPixels * q.raysPerSlot);
         hipEvent_t* marks = nullptr;
         if (timeIt && ctx->marksUsed + 4 > 4 * kMaxTimedLaunches) { // a frame of very many batches, or many unread frames
             HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -684,7 +697,7 @@ static int launchBatches(rt_ctx* ctx, QueueFrame& q, const WfBuffers& wb, const 
             HIP_TRY(ctx, launchWavefrontGlossy(q.dof, collect, q.pathBlocks, q.shadowBlocks, kBlockThreads, lds, stream, ctx->scene, cam, ft, fr,
                               wp, wb, dCounters, dOut, pathKnobs, shadowKnobs, marks, ctx->numCU));
         else
-            HIP_TRY(ctx, launchWavefront(q.dof, collect, q.transp, q.pathBlocks, q.shadowBlocks, kBlockThreads, lds, stream, ctx->scene, cam, ft,
+            HIP_TRY(ctx, launchWavefront(q.dof, collect, q.transp, q.motion, q.pathBlocks, q.shadowBlocks, kBlockThreads, lds, stream, ctx->scene, cam, ft,
                               fr, wp, wb, dCounters, dOut, pathKnobs, shadowKnobs, marks, ctx->numCU));
     }
     return RT_OK;
@@ -750,16 +763,18 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
         return fail(ctx, RT_ERR_STATE, "render: launch geometry not prepared (rt_scene_upload and rt_features_set do that)");
     // Glossy reflections take the queue-based renderer too (a tree kernel walks each pixel's radiance rays, everything
     // else is shared with the mirror case), except together with transparency, which only the per-pixel kernel combines.
+    // So does motion blur (motionOnQueues).
     const bool glossyOn = F.enableGlossyReflection && F.enableReflections;
     const bool glossyWf = glossyOn && !ctx->forcePerPixel && !F.enableTransparency && !motionBlurOn(F);
-    const bool perPixel = ctx->forcePerPixel || (glossyOn && !glossyWf) || motionBlurOn(F);
+    const bool motionWf = motionOnQueues(F) && !ctx->forcePerPixel;
+    const bool perPixel = ctx->forcePerPixel || (glossyOn && !glossyWf) || (motionBlurOn(F) && !motionWf);
     int rc = RT_OK;
     if (perPixel) {
         rc = launchPerPixel(ctx, cam, ft, fr, lds, collect, occReady, dCounters, dOut, stream);
     } else { // the queue-based renderer: work items are camera rays and light samples
         QueueFrame q;
         WfBuffers wb {};
-        rc = queueFrame(ctx, ft, fr, arena, lds, glossyWf, collect, occReady, q);
+        rc = queueFrame(ctx, ft, fr, arena, lds, glossyWf, motionWf, collect, occReady, q);
         if (rc == RT_OK) {
             candidateTiles(ctx, *camera, fr, width, height);
             rc = workingBuffers(ctx, q, fr, arena, stream, wb);

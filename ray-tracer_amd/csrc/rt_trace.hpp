@@ -68,9 +68,11 @@ __device__ __forceinline__ f3 rcp3(f3 d)
 // (see Tracer::settleTie).  Out of line on purpose: it runs for one ray in millions and must not
 // weigh on the register budget of the loops that call it.  `stk` is the calling lane's column of
 // the LDS stack (entries `stride` words apart), empty by now; returns (closest t as bits, primitive or kHitNone).
-// With a Mover, the nodes and triangles are those of the moved copy of the scene: the move is monotone per
+// MOVED (with a Mover): the nodes and triangles are those of the moved copy of the scene: the move is monotone per
 // coordinate, so the box of a set of moved vertices is the moved box, and the copy's tree has the rest
 // tree's shape wherever the centroids keep their order (they do but for pairs a rounding apart).
+// (A function of its own per case: what the callers of the plain one must keep out of its way is what IT uses.)
+template <bool MOVED = false>
 static __device__ __attribute__((noinline)) uint2 replayReference(const uint4* __restrict__ nodes, const float4* __restrict__ tris, LdsWords stk,
     uint32_t stride, float ox, float oy, float oz, float dx, float dy, float dz, float tmax, const Mover* mv = nullptr)
 {
@@ -81,7 +83,7 @@ static __device__ __attribute__((noinline)) uint2 replayReference(const uint4* _
         const uint4 a = nodes[2u * node], b = nodes[2u * node + 1u];
         f3 l3 = { __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z) };
         f3 h3 = { __uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y) };
-        if (mv) {
+        if (MOVED) {
             l3 = moved(*mv, l3);
             h3 = moved(*mv, h3);
         }
@@ -104,7 +106,7 @@ static __device__ __attribute__((noinline)) uint2 replayReference(const uint4* _
             for (uint32_t i = first; i < first + w.w; i++) {
                 float t;
                 bool hit;
-                if (mv) {
+                if (MOVED) {
                     const TriRec rest = loadTri(tris, i);
                     hit = triangleTest(triFromVertices(moved(*mv, rest.v0), moved(*mv, rest.v1), moved(*mv, rest.v2)), O, D, tmax, t);
                 } else {
@@ -561,7 +563,7 @@ struct Tracer {
         if (accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr && r.hitPrim >= 0 && !r.tie && !surelyReached(r))
             r.tie = true;
         if (__builtin_expect(r.tie, 0) && sc.refNodes != nullptr && accel) {
-            const uint2 res = replayReference(sc.refNodes, sc.tris, stk, stride, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.slen,
+            const uint2 res = replayReference<MOTION>(sc.refNodes, sc.tris, stk, stride, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.slen,
                 MOTION ? &r.mv : nullptr);
             r.tmax = __uint_as_float(res.x);
             r.hitPrim = (int)res.y;

@@ -1,5 +1,5 @@
-// rt_wavefront.hip -- the queue-based (wavefront) form of renderImage for
-// gfx950, used unless glossy reflection is on.
+// rt_wavefront.hip -- the queue-based (wavefront) form of renderImage for gfx950: mirror reflections,
+// transparency, glossy reflections (glossyTreeKernel) and motion blur (the MOTION variants; rt_wavefront.hpp).
 //
 // The reference consumes ONE Sampler stream per pixel, depth first
 // (src/render.cpp:34-39).  Which rays a pixel's ray tree contains, though, does
@@ -152,7 +152,10 @@ __device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
 #endif
 constexpr uint32_t kCamPerLane = RT_CAM_PER_LANE; // camera rays per lane: one queue reservation per 256 times as many rays
 
-template <bool DOF>
+// MOTION: a path belongs to a (pixel, time sample) pair.  The pair's time is draw m + 1 of the pixel's stream and the
+// pair is rendered with the stream as it stands after that draw (src/extra.cpp:145-204); the scene's box moves with
+// the time, so every ray is queued and the traversal kernel does the root test on the moved copy.
+template <bool DOF, bool MOTION = false>
 __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const DevCamera cam, const DevFeat ft, const DevFrame fr,
     const WfParams wp, const WfBuffers wb, DevCounters* __restrict__ ctr)
 {
@@ -160,9 +163,11 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
     __shared__ uint32_t blockBase;
     const Tracer<false> tracer { sc, ft.accel, (LdsWords)0 };
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t total = wp.nSlots * wp.R;
+    const uint32_t M = MOTION ? (uint32_t)ft.motionSamples : 1u; // time samples per pixel
+    const uint32_t total = wp.nSlots * M * wp.R;
     bool queue[kCamPerLane], enters[kCamPerLane];
     f3 o[kCamPerLane], d[kCamPerLane];
+    float when[MOTION ? kCamPerLane : 1u];
     unsigned long long qm[kCamPerLane];
 #pragma unroll
     for (uint32_t j = 0; j < kCamPerLane; j++) {
@@ -170,8 +175,14 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
         queue[j] = enters[j] = false;
         o[j] = d[j] = mk3(0.0f);
         if (path < total) {
-            const uint32_t pixel = fastDiv(path, wp.divR);
-            const uint32_t slot = wp.slotBegin + pixel, i = path - pixel * wp.R;
+            const uint32_t pixel = fastDiv(path, wp.divR); // (MOTION: the sample slot)
+            const uint32_t i = path - pixel * wp.R;
+            uint32_t pslot = pixel, m = 0;
+            if (MOTION) {
+                pslot = pixel / M;
+                m = pixel - pslot * M;
+            }
+            const uint32_t slot = wp.slotBegin + pslot;
             int px, py;
             if (slotToPixel(fr, slot, px, py)) { // padding pixels of partial edge tiles have no rays
                 // A pixel from which the scene's box cannot be seen: every ray of it misses, and unless the
@@ -179,7 +190,11 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
                 // (combineKernel knows the same rectangle and writes such a pixel's black without reading anything)
                 if (!ft.envMap && !seesScene(fr, px, py)) {
                 } else {
-                const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
+                uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
+                if (MOTION) {
+                    seed = lcgSkip(seed, m);
+                    when[j] = next1d(seed);
+                }
                 const uint32_t dofN = (DOF && ft.dof) ? ft.dofSamples : 1u;
                 const uint32_t sample = (DOF && ft.dof) ? fastDiv(i, ft.divDof) : i; // i / dofN
                 uint32_t sPix = (ft.spp > 1) ? lcgSkip(seed, 2u * sample) : seed;
@@ -188,9 +203,9 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
                 cameraRay<DOF>(cam, ft, fr, px, py, sample * dofN, sPix, sLens, pof, o[j], d[j]);
                 // (the root test is widened against rounding; the host sized the ray queue and the hit pools by the pixels
                 // of the rectangle alone, and no ray from outside it can enter the box itself)
-                enters[j] = ft.accel && seesScene(fr, px, py) && tracer.entersScene(o[j], rcp3(d[j]));
+                enters[j] = !MOTION && ft.accel && seesScene(fr, px, py) && tracer.entersScene(o[j], rcp3(d[j]));
                 // without the acceleration structure, or with spheres in the scene, every ray has work left
-                queue[j] = enters[j] || !ft.accel || sc.nSpheres != 0;
+                queue[j] = MOTION || enters[j] || !ft.accel || sc.nSpheres != 0;
                 if (!queue[j]) {
                     wb.pathHead[path] = kPathMiss;
                     wb.pathCount[path] = 0;
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
         if (queue[j]) {
             const uint32_t path = (blockIdx.x * kCamPerLane + j) * 256u + threadIdx.x;
             wb.camRays[2u * (size_t)idx + 0] = make_float4(o[j].x, o[j].y, o[j].z, __uint_as_float(path));
-            wb.camRays[2u * (size_t)idx + 1] = make_float4(d[j].x, d[j].y, d[j].z, enters[j] ? 1.0f : 0.0f);
+            wb.camRays[2u * (size_t)idx + 1] = make_float4(d[j].x, d[j].y, d[j].z, MOTION ? when[MOTION ? j : 0u] : (enters[j] ? 1.0f : 0.0f));
         }
     }
 }
@@ -243,14 +258,16 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
 #else
 // (four waves per SIMD is what the kernel's registers allowed before the check of Tracer::surelyReached came to
 // sit in its shading path; held to that, it keeps them for two spilled registers outside the loops)
-#define RT_PATH_ATTR __attribute__((amdgpu_waves_per_eu(STATS ? 1 : 4)))
+#define RT_PATH_ATTR __attribute__((amdgpu_waves_per_eu((STATS || MOTION) ? 1 : 4)))
 #endif
-template <bool STATS, bool TRANSP>
+// MOTION: the queued ray's record carries its time; the ray and the mirror chain behind it meet the copy of the scene
+// moved to that time (Tracer<., true>, RayState::mv).
+template <bool STATS, bool TRANSP, bool MOTION = false>
 __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<STATS> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
+    const Tracer<STATS, MOTION> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = ctr->camQueued.v;
     // node slots a wave reserves per atomic: about what its share of the rays will fill, so that a small
@@ -296,7 +313,10 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
             if (!have && !dead && !want) {
                 const float4 c0 = wb.camRays[2u * (size_t)item + 0], c1 = wb.camRays[2u * (size_t)item + 1];
                 path = __float_as_uint(c0.w);
-                if (c1.w != 0.0f)
+                if (MOTION) {
+                    r.mv = makeMover(c1.w, ft.movement);
+                    tracer.launch(r, { c0.x, c0.y, c0.z }, { c1.x, c1.y, c1.z }, kFltMax, K_RADIANCE);
+                } else if (c1.w != 0.0f)
                     tracer.launchInside(r, { c0.x, c0.y, c0.z }, { c1.x, c1.y, c1.z }, kFltMax, K_RADIANCE);
                 else
                     tracer.launch(r, { c0.x, c0.y, c0.z }, { c1.x, c1.y, c1.z }, kFltMax, K_RADIANCE);
@@ -333,7 +353,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
                         }
                     }
                 } else {
-                    const HitCtx h = shadeHit(sc, ft, r);
+                    const HitCtx h = shadeHit<MOTION>(sc, ft, r);
                     // One node per shaded hit.  Every wave owns a block of nodeBlock (>= 64) consecutive slots of
                     // the pool and hands them out itself; only a new block costs an atomic (one address
                     // takes well under a hundred of them per microsecond, far fewer than there are hits).
@@ -768,13 +788,14 @@ __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene
 // ---------------------------------------------------------------------------
 // 2. per pixel: how many hits precede each of its paths
 // ---------------------------------------------------------------------------
-__global__ void prefixKernel(const DevFrame fr, const WfParams wp, const WfBuffers wb)
+// M: time samples per pixel with motion blur, else 0
+__global__ void prefixKernel(const DevFrame fr, const WfParams wp, const WfBuffers wb, uint32_t M)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= wp.nSlots)
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; // sample slot
+    if (s >= wp.nSlots * (M ? M : 1u))
         return;
     int px, py;
-    if (!slotToPixel(fr, wp.slotBegin + s, px, py) || !seesScene(fr, px, py)) // (no hits, no bases to count)
+    if (!slotToPixel(fr, wp.slotBegin + (M ? s / M : s), px, py) || !seesScene(fr, px, py)) // (no hits, no bases to count)
         return;
     uint32_t base = 0;
     if ((wp.R & 3u) == 0u) { // four paths at a time: one 4-B load of counts, one 16-B store of bases
@@ -882,12 +903,23 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
                 const float4 a0 = wb.nodeA[4u * (size_t)node];
                 const f3 P = { a0.x, a0.y, a0.z };
                 int px, py;
-                slotToPixel(fr, wp.slotBegin + fastDiv(path, wp.divR), px, py);
+                uint32_t pslot = fastDiv(path, wp.divR), before = 0;
+                if (ft.motion) { // motion blur: the draws of the pixel's stream up to and with the time of the path's sample slot
+                    const uint32_t pair = pslot, M = (uint32_t)ft.motionSamples;
+                    pslot = pair / M;
+                    before = pair - pslot * M + 1u;
+                }
+                slotToPixel(fr, wp.slotBegin + pslot, px, py);
                 const uint32_t seed = (uint32_t)(fr.height * px + py);
+                float when = 0.0f; // the time the shadow ray is traced at
+                if (ft.motion) {
+                    uint32_t st = lcgSkip(seed, before - 1u);
+                    when = next1d(st);
+                }
                 // where the hit's light-sample draws begin: with glossy reflections the tree kernel knew and
                 // wrote it down; otherwise it follows from the number of hits before this one in its pixel
                 const uint32_t hitDraws = wp.absDraws ? ordinal : wp.drawsPerHit * (wb.pathBase[path] + ordinal);
-                uint32_t s = lcgSkip(seed, wp.mainStart + hitDraws + drawPrefix + slot * perSample);
+                uint32_t s = lcgSkip(seed, before + wp.mainStart + hitDraws + drawPrefix + slot * perSample);
                 f3 pos, col;
                 if (light.type == 0) {
                     pos = ld3(light.v + 0);
@@ -911,13 +943,13 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
                 if (late) {
                     float4* sr = wb.srays + 3u * (size_t)item;
                     sr[0] = make_float4(pos.x, pos.y, pos.z, len);
-                    sr[1] = make_float4(d.x, d.y, d.z, 0.0f);
+                    sr[1] = make_float4(d.x, d.y, d.z, when);
                     sr[2] = make_float4(col.x, col.y, col.z, 0.0f);
                     wb.svis[item] = 1; // visible unless the traversal finds an occluder
                 } else {
                     float4* sr = wb.srays + 2u * (size_t)item;
                     sr[0] = make_float4(pos.x, pos.y, pos.z, len);
-                    sr[1] = make_float4(d.x, d.y, d.z, 0.0f);
+                    sr[1] = make_float4(d.x, d.y, d.z, when);
                     // the sample's light as if it arrived (src/light.cpp:171-186); the traversal clears it if not
                     f3 c = { 0.0f, 0.0f, 0.0f };
                     if (!isZero(col)) {
@@ -948,12 +980,15 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
 #define RT_TRANSP_WAVES 6
 #endif
 #define RT_SHADOW_ATTR(stats, transp) __attribute__((amdgpu_waves_per_eu((stats) ? 1 : ((transp) ? RT_TRANSP_WAVES : RT_SHADOW_WAVES))))
-template <bool STATS, bool TRANSP>
-__global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR(STATS, TRANSP) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+// MOTION: the ray's record carries its time, the ray meets the copy of the scene moved to that time, and a hit the
+// reference's own boxes may have kept it from is settled on the spot, as the per-pixel kernel does (Tracer::settleTie),
+// instead of going on the list of shadowRedoKernel.  (No register budget forced: the move needs its own.)
+template <bool STATS, bool TRANSP, bool MOTION = false>
+__global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR(STATS || MOTION, TRANSP) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<STATS> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
+    const Tracer<STATS, MOTION> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nNodesAll = ctr->nodes.v < wb.maxNodes ? ctr->nodes.v : wb.maxNodes;
     const uint32_t total = ft.shadows ? nNodesAll * wp.slots : 0u; // shadows off: no ray at all (src/light.cpp:270-272)
@@ -984,6 +1019,8 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR(STATS, TRANSP) void s
             const float4* sr = wb.srays + (TRANSP ? 3u : 2u) * (size_t)item;
             const float4 a = sr[0], b = sr[1];
             if (a.w >= 0.0f) { // a negative length marks the slot of a node that holds no hit
+                if (MOTION)
+                    r.mv = makeMover(b.w, ft.movement);
                 tracer.launch(r, { a.x, a.y, a.z }, { b.x, b.y, b.z }, a.w, TRANSP ? K_SHADOW_CLOSEST : K_SHADOW_ANY);
                 have = true;
                 if (TRANSP) {
@@ -1008,6 +1045,8 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR(STATS, TRANSP) void s
                 }
         }
         if (have && !r.active) {
+            if (MOTION)
+                tracer.settleTie(r);
             if (sc.nSpheres)
                 tracer.spheres(r);
             if (!TRANSP) {
@@ -1017,7 +1056,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR(STATS, TRANSP) void s
                     // An occluder the reference's own box tests may have kept it from (Tracer::surelyReached) proves
                     // nothing: the sample goes on a list and shadowRedoKernel follows it the reference's way.
                     // (A visible sample needs no such care: what the reference finds is among what was found here.)
-                    if (r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr && !tracer.surelyReached(r)) {
+                    if (!MOTION && r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr && !tracer.surelyReached(r)) {
                         wb.redo[atomicAdd(&ctr->redo.v, 1u)] = item;
                     } else {
                         float* dst = wb.contrib + 3u * (size_t)item;
@@ -1406,26 +1445,35 @@ __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const De
     // a pixel that cannot see the scene's box: every ray of it missed; black unless the background has a colour of
     // its own (the camera kernel wrote nothing for it)
     const bool sees = valid && (ft.envMap || seesScene(fr, px, py));
-    f3 L = mk3(0.0f);
-    for (uint32_t base = 0; base < wp.R; base += perRound) {
-        const uint32_t i = base + j;
-        f3 v = mk3(0.0f);
-        if (sees && i < wp.R)
-            v = MODE == 2 ? pathValueGlossy(sc, ft, wp, wb, s * wp.R + i)
-                : (MODE == 1 ? pathValueTree(sc, ft, wp, wb, s * wp.R + i) : pathValue(sc, ft, wp, wb, s * wp.R + i));
-        vals[3u * threadIdx.x + 0] = v.x;
-        vals[3u * threadIdx.x + 1] = v.y;
-        vals[3u * threadIdx.x + 2] = v.z;
-        __syncthreads();
-        if (valid && j == 0) {
-            const uint32_t n = (wp.R - base < perRound) ? wp.R - base : perRound;
-            for (uint32_t k = 0; k < n; k++)
-                L = L + ld3(vals + 3u * (threadIdx.x + k));
+    // motion blur: the pixel's sample slots one after the other, each the mean of its camera rays; then their mean
+    // (src/extra.cpp:205-208)
+    const uint32_t nSamples = ft.motion ? (uint32_t)ft.motionSamples : 1u;
+    f3 L = mk3(0.0f), Lmo = mk3(0.0f);
+    for (uint32_t m = 0; m < nSamples; m++) {
+        const uint32_t first = (s * nSamples + m) * wp.R; // the sample slot's first path
+        L = mk3(0.0f);
+        for (uint32_t base = 0; base < wp.R; base += perRound) {
+            const uint32_t i = base + j;
+            f3 v = mk3(0.0f);
+            if (sees && i < wp.R)
+                v = MODE == 2 ? pathValueGlossy(sc, ft, wp, wb, first + i)
+                    : (MODE == 1 ? pathValueTree(sc, ft, wp, wb, first + i) : pathValue(sc, ft, wp, wb, first + i));
+            vals[3u * threadIdx.x + 0] = v.x;
+            vals[3u * threadIdx.x + 1] = v.y;
+            vals[3u * threadIdx.x + 2] = v.z;
+            __syncthreads();
+            if (valid && j == 0) {
+                const uint32_t n = (wp.R - base < perRound) ? wp.R - base : perRound;
+                for (uint32_t k = 0; k < n; k++)
+                    L = L + ld3(vals + 3u * (threadIdx.x + k));
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        if (ft.motion)
+            Lmo = Lmo + L / (float)wp.R;
     }
     if (valid && j == 0) {
-        const f3 c = L / (float)wp.R;
+        const f3 c = ft.motion ? Lmo / (float)ft.motionSamples : L / (float)wp.R;
         const uint32_t slot = wp.slotBegin + s;
         const size_t idx = fr.packed ? (size_t)slot : ((size_t)(fr.height - 1 - py) * fr.width + px);
         out[3 * idx + 0] = c.x;
@@ -1439,27 +1487,31 @@ __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const De
 // ---------------------------------------------------------------------------
 typedef void (*ShadowFn)(const DevScene, const DevFeat, const WfParams, const WfBuffers, DevCounters*, int);
 
-static ShadowFn pathVariant(bool stats, bool transp)
+static ShadowFn pathVariant(bool stats, bool transp, bool motion = false)
 {
+    if (motion) // (without transparency: together they stay with the per-pixel kernel)
+        return stats ? pathKernel<true, false, true> : pathKernel<false, false, true>;
     if (transp)
         return stats ? pathKernel<true, true> : pathKernel<false, true>;
     return stats ? pathKernel<true, false> : pathKernel<false, false>;
 }
-static ShadowFn shadowVariant(bool stats, bool transp)
+static ShadowFn shadowVariant(bool stats, bool transp, bool motion = false)
 {
+    if (motion)
+        return stats ? shadowTraceKernel<true, false, true> : shadowTraceKernel<false, false, true>;
     if (transp)
         return stats ? shadowTraceKernel<true, true> : shadowTraceKernel<false, true>;
     return stats ? shadowTraceKernel<true, false> : shadowTraceKernel<false, false>;
 }
 
-hipError_t wavefrontOccupancy(bool stats, bool transp, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks)
+hipError_t wavefrontOccupancy(bool stats, bool transp, bool motion, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks)
 {
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(pathBlocks, pathVariant(stats, transp), blockThreads, ldsBytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(pathBlocks, pathVariant(stats, transp, motion), blockThreads, ldsBytes);
     if (e != hipSuccess)
         return e;
     if (getenv("RT_AMD_DEBUG_OCCUPANCY")) { // what bounds the resident blocks: registers or LDS
         for (int k = 0; k < 2; k++) {
-            const void* fn = k ? (const void*)shadowVariant(stats, transp) : (const void*)pathVariant(stats, transp);
+            const void* fn = k ? (const void*)shadowVariant(stats, transp, motion) : (const void*)pathVariant(stats, transp, motion);
             hipFuncAttributes a {};
             int noLds = 0, withLds = 0;
             (void)hipFuncGetAttributes(&a, fn);
@@ -1469,24 +1521,27 @@ hipError_t wavefrontOccupancy(bool stats, bool transp, int blockThreads, size_t 
                 k ? "shadow" : "path", a.numRegs, a.sharedSizeBytes, ldsBytes, noLds, withLds);
         }
     }
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(shadowBlocks, shadowVariant(stats, transp), blockThreads, ldsBytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(shadowBlocks, shadowVariant(stats, transp, motion), blockThreads, ldsBytes);
 }
 
-hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
+hipError_t launchWavefront(bool dof, bool stats, bool transp, bool motion, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
     const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU)
 {
     // marks (optional, 3 events): after the path kernel, before and after the shadow-ray traversal
-    const int cb = (int)(((size_t)wp.nSlots * wp.R + 256 * kCamPerLane - 1) / (256 * kCamPerLane));
-    if (dof)
+    const uint32_t nSampleSlots = wp.nSlots * (motion ? (uint32_t)ft.motionSamples : 1u);
+    const int cb = (int)(((size_t)nSampleSlots * wp.R + 256 * kCamPerLane - 1) / (256 * kCamPerLane));
+    if (motion)
+        hipLaunchKernelGGL((cameraKernel<false, true>), dim3(cb), dim3(256), 0, stream, sc, cam, ft, fr, wp, wb, ctr);
+    else if (dof)
         hipLaunchKernelGGL(cameraKernel<true>, dim3(cb), dim3(256), 0, stream, sc, cam, ft, fr, wp, wb, ctr);
     else
         hipLaunchKernelGGL(cameraKernel<false>, dim3(cb), dim3(256), 0, stream, sc, cam, ft, fr, wp, wb, ctr);
-    hipLaunchKernelGGL(pathVariant(stats, transp), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActive);
+    hipLaunchKernelGGL(pathVariant(stats, transp, motion), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActive);
     if (marks)
         (void)hipEventRecord(marks[0], stream);
-    const int pb = (int)((wp.nSlots + 255) / 256);
-    hipLaunchKernelGGL(prefixKernel, dim3(pb), dim3(256), 0, stream, fr, wp, wb);
+    const int pb = (int)((nSampleSlots + 255) / 256);
+    hipLaunchKernelGGL(prefixKernel, dim3(pb), dim3(256), 0, stream, fr, wp, wb, motion ? (uint32_t)ft.motionSamples : 0u);
     // Six blocks of this kernel fit a compute unit, so a grid of eight per unit runs a full round and then a third of
     // one: 0.70 ms for the headline frame's samples alone, against 0.57 with 6, 12 or 24 per unit.  With several
     // frames in flight that last third is where the other frames' traversal waves get in, and the order reverses:
@@ -1498,12 +1553,12 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, in
     hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * RT_GEN_BLOCKS), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr, sc.lights);
     if (marks)
         (void)hipEventRecord(marks[1], stream);
-    hipLaunchKernelGGL(shadowVariant(stats, transp), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
+    hipLaunchKernelGGL(shadowVariant(stats, transp, motion), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
     if (marks)
         (void)hipEventRecord(marks[2], stream);
     if (transp) // (otherwise the samples were shaded when they were generated)
         hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
-    else if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr)
+    else if (!motion && ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr)
         hipLaunchKernelGGL(shadowRedoKernel, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr);
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
     const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);

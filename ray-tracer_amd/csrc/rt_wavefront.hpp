@@ -45,6 +45,12 @@ struct WfBuffers {
     uint32_t maxNodes;
 };
 
+// Motion blur (src/extra.cpp:121-211; DevFeat::motion, ::motionSamples = M): M time samples per pixel, each rendered like
+// a pixel of its own -- its own stretch of the pixel's sampler stream, its own copy of the scene -- and the pixel's colour
+// is their mean.  Every (pixel slot, time sample) pair is a "sample slot", pair = slot * M + m, and takes a pixel slot's
+// place wherever paths are indexed: path = pair * R + camera ray.  Without motion blur a sample slot is a pixel slot.
+// (Nothing about it is kept in WfParams: the struct sits in the kernels' argument block ahead of WfBuffers, and the
+// path kernel's register allocation did not take its growing well.)
 struct WfParams {
     uint32_t slotBegin;  // first local pixel slot of this batch
     uint32_t nSlots;     // pixel slots in this batch (multiple of 64)
@@ -64,8 +70,8 @@ struct WfParams {
     uint32_t absDraws;   // 1: NodeB::ordinal is the position of the hit's light-sample draws itself (glossy reflections)
 };
 
-hipError_t wavefrontOccupancy(bool stats, bool transp, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
-hipError_t launchWavefront(bool dof, bool stats, bool transp, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
+hipError_t wavefrontOccupancy(bool stats, bool transp, bool motion, int blockThreads, size_t ldsBytes, int* pathBlocks, int* shadowBlocks);
+hipError_t launchWavefront(bool dof, bool stats, bool transp, bool motion, int pathBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes,
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
     const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
 

@@ -130,3 +130,72 @@ def test_motion_blur_corner_cases(ctx):
     ctx.deinterleave(packed.data_ptr(), w, h, world, frame.data_ptr(), 0)
     ctx.sync(0)
     assert np.array_equal(frame.cpu().numpy().reshape(h, w, 3).view(np.uint32), whole.view(np.uint32))
+
+
+def test_motion_blur_on_the_queue_based_renderer():
+    """Motion blur without transparency or glossy reflections runs on the queue-based renderer: every (pixel, time
+    sample) pair takes a pixel's place in the queues, its rays carry the pair's time and meet the scene moved to it, and
+    the combine takes the mean over a pixel's pairs.  Bit for bit against the per-pixel kernel (which the tests above
+    hold against the oracle, as they do the default renderer): one camera ray per sample and several, mirror chains,
+    all three kinds of light, an environment map, spheres, pixel batches (a small workspace), the counting kernels,
+    shards, and the entry point that allocates nothing."""
+    import copy
+    import torch
+    scn = copy.deepcopy(common.scene("CornellBox", env_map=True))
+    scn.lights = [sio.cornell_parallelogram_light(), sio.point_light((0.2, 0.3, 0.4), (0.6, 0.5, 0.4)),
+                  sio.segment_light((-0.3, 0.4, -0.2), (0.3, 0.4, 0.2), (1, 0, 0), (0, 0, 1))]
+    spheres = sio.load_scene_prebuilt("Spheres", common.DATA)
+    w, h = 45, 27  # (partial tiles on both edges)
+    cases = [
+        (scn, sio.default_camera(w, h), dict(motionBlurSamples=1, movement=0.5, numShadowSamples=1)),
+        (scn, sio.default_camera(w, h), dict(motionBlurSamples=3, movement=0.7, numShadowSamples=2, enableReflections=1, maxRayDepth=3,
+                                             enableEnvironmentMap=1)),
+        (scn, sio.default_camera(w, h), dict(motionBlurSamples=5, movement=0.3, numShadowSamples=3, numPixelSamples=4,
+                                             enableJitteredSampling=1, enableReflections=1, maxRayDepth=2)),
+        (scn, sio.default_camera(w, h), dict(motionBlurSamples=2, movement=1.1, numShadowSamples=2, numPixelSamples=3,
+                                             enableShadows=0)),
+        (spheres, sio.default_camera(w, h, distance=6.0, look_at=(0, 0, 12), rotation_deg=(0, 180, 0)),
+         dict(motionBlurSamples=4, movement=0.5, numShadowSamples=1, enableReflections=1)),
+    ]
+    for k, (s, cam, kw) in enumerate(cases):
+        kw = dict(dict(enableShading=1, enableShadows=1, shadingModel=2, enableNormalInterp=1), **kw)
+        f = common.features(enableMotionBlur=1, **kw)
+        images, rays = {}, {}
+        for name, opts in (("queues", dict(per_pixel=0)), ("queues, small workspace", dict(per_pixel=0, workspace_bytes=2 << 20)),
+                           ("per pixel", dict(per_pixel=1))):
+            c = capi.Context(0, **opts)
+            c.upload_scene(s)
+            c.set_features(f)
+            images[name], st = c.render(cam, w, h)
+            rays[name] = st["rays"]
+            if name == "queues":  # the counting kernels, packed shards, and the static scratch
+                buf = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+                st2 = c.render_device(cam, w, h, buf.data_ptr(), buf.numel(), 0, 1, 0, collect_stats=True)
+                assert st2["rays"] == st["rays"], (k, st2["rays"], st["rays"])
+                images["queues, counting"] = buf.cpu().numpy().reshape(h, w, 3)
+                buf.zero_()
+                c.render_device_noalloc(cam, w, h, buf.data_ptr(), buf.numel(), 0, 1, 0)
+                c.sync(0)
+                images["queues, no allocation"] = buf.cpu().numpy().reshape(h, w, 3)
+            c.close()
+        assert images["per pixel"].any(), k
+        assert rays["queues"] == rays["per pixel"] == rays["queues, small workspace"], (k, rays)
+        for name in images:
+            assert np.array_equal(images[name].view(np.uint32), images["per pixel"].view(np.uint32)), \
+                (k, name, common.image_error(images[name], images["per pixel"]))
+    # shards of the frame, packed
+    s, cam, kw = cases[2]
+    f = common.features(enableMotionBlur=1, enableShading=1, enableShadows=1, shadingModel=2, **kw)
+    for shard in range(3):
+        outs = []
+        for opts in (dict(per_pixel=0), dict(per_pixel=1)):
+            c = capi.Context(0, **opts)
+            c.upload_scene(s)
+            c.set_features(f)
+            n = capi.shard_floats(w, h, shard, 3)
+            buf = torch.zeros(n, dtype=torch.float32, device="cuda")
+            c.render_device(cam, w, h, buf.data_ptr(), n, shard, 3, 0)
+            c.sync(0)
+            outs.append(buf.cpu().numpy())
+            c.close()
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)) and outs[0].any(), shard
