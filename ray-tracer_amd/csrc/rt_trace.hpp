@@ -562,12 +562,14 @@ struct Tracer {
     {
         if (accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr && r.hitPrim >= 0 && !r.tie && !surelyReached(r))
             r.tie = true;
+#ifndef RT_PROBE_NO_REPLAY // (experiment: what the call costs the kernels that hold it; results wrong where ties occur)
         if (__builtin_expect(r.tie, 0) && sc.refNodes != nullptr && accel) {
             const uint2 res = replayReference<MOTION>(sc.refNodes, sc.tris, stk, stride, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.slen,
                 MOTION ? &r.mv : nullptr);
             r.tmax = __uint_as_float(res.x);
             r.hitPrim = (int)res.y;
         }
+#endif
         r.tie = false;
     }
 

@@ -258,7 +258,10 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
 #else
 // (four waves per SIMD is what the kernel's registers allowed before the check of Tracer::surelyReached came to
 // sit in its shading path; held to that, it keeps them for two spilled registers outside the loops)
-#define RT_PATH_ATTR __attribute__((amdgpu_waves_per_eu((STATS || MOTION) ? 1 : 4)))
+#ifndef RT_MOTION_PATH_WAVES
+#define RT_MOTION_PATH_WAVES 1 // (the motion-blur variant: 1 = whatever its registers leave)
+#endif
+#define RT_PATH_ATTR __attribute__((amdgpu_waves_per_eu(STATS ? 1 : (MOTION ? RT_MOTION_PATH_WAVES : 4))))
 #endif
 // MOTION: the queued ray's record carries its time; the ray and the mirror chain behind it meet the copy of the scene
 // moved to that time (Tracer<., true>, RayState::mv).
@@ -979,12 +982,14 @@ __global__ __launch_bounds__(256) void shadowGenKernel(const DevScene sc, const 
 #ifndef RT_TRANSP_WAVES
 #define RT_TRANSP_WAVES 6
 #endif
+#ifndef RT_MOTION_SHADOW_WAVES
+#define RT_MOTION_SHADOW_WAVES 1
+#endif
 #define RT_SHADOW_ATTR(stats, transp) __attribute__((amdgpu_waves_per_eu((stats) ? 1 : ((transp) ? RT_TRANSP_WAVES : RT_SHADOW_WAVES))))
-// MOTION: the ray's record carries its time, the ray meets the copy of the scene moved to that time, and a hit the
-// reference's own boxes may have kept it from is settled on the spot, as the per-pixel kernel does (Tracer::settleTie),
-// instead of going on the list of shadowRedoKernel.  (No register budget forced: the move needs its own.)
+// MOTION: the ray's record carries its time and the ray meets the copy of the scene moved to that time.
+// (No register budget forced: the move needs its own.)
 template <bool STATS, bool TRANSP, bool MOTION = false>
-__global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR(STATS || MOTION, TRANSP) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(STATS ? 1 : (MOTION ? RT_MOTION_SHADOW_WAVES : (TRANSP ? RT_TRANSP_WAVES : RT_SHADOW_WAVES))))) void shadowTraceKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
@@ -1045,8 +1050,6 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR(STATS || MOTION, TRAN
                 }
         }
         if (have && !r.active) {
-            if (MOTION)
-                tracer.settleTie(r);
             if (sc.nSpheres)
                 tracer.spheres(r);
             if (!TRANSP) {
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_SHADOW_ATTR(STATS || MOTION, TRAN
                     // An occluder the reference's own box tests may have kept it from (Tracer::surelyReached) proves
                     // nothing: the sample goes on a list and shadowRedoKernel follows it the reference's way.
                     // (A visible sample needs no such care: what the reference finds is among what was found here.)
-                    if (!MOTION && r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr && !tracer.surelyReached(r)) {
+                    if (r.hitPrim >= 0 && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr && !tracer.surelyReached(r)) {
                         wb.redo[atomicAdd(&ctr->redo.v, 1u)] = item;
                     } else {
                         float* dst = wb.contrib + 3u * (size_t)item;
@@ -1199,7 +1202,9 @@ __device__ __attribute__((noinline)) void redoTransparentSample(const DevScene& 
 // Without transparency: the light samples the traversal kernel would not decide (their occluder lies in a leaf the
 // reference's own box tests may have turned the ray away from), each traced again in the reference's own order
 // of tests over the caller's nodes; src/light.cpp:101-107 on that result.  A handful per frame, if any.
-__global__ __launch_bounds__(256) void shadowRedoKernel(const DevScene sc, const WfBuffers wb, DevCounters* __restrict__ ctr)
+// MOTION: in the copy of the scene moved to the ray's time (its record carries it).
+template <bool MOTION = false>
+__global__ __launch_bounds__(256) void shadowRedoKernel(const DevScene sc, const WfBuffers wb, DevCounters* __restrict__ ctr, float movement)
 {
     __shared__ uint32_t redoStack[kMaxStack * 256];
     const uint32_t n = ctr->redo.v;
@@ -1208,12 +1213,21 @@ __global__ __launch_bounds__(256) void shadowRedoKernel(const DevScene sc, const
         const float4* sr = wb.srays + 2u * (size_t)item;
         const float4 a = sr[0], b = sr[1];
         const f3 o = { a.x, a.y, a.z }, d = { b.x, b.y, b.z };
-        const uint2 res = replayReference(sc.refNodes, sc.tris, (LdsWords)(redoStack + threadIdx.x), 256u, o.x, o.y, o.z, d.x, d.y, d.z, a.w);
+        Mover mv;
+        if (MOTION)
+            mv = makeMover(b.w, movement);
+        const uint2 res = replayReference<MOTION>(sc.refNodes, sc.tris, (LdsWords)(redoStack + threadIdx.x), 256u, o.x, o.y, o.z, d.x, d.y, d.z, a.w,
+            MOTION ? &mv : nullptr);
         float t = __uint_as_float(res.x);
         bool hit = (int)res.y != kHitNone;
         for (int s = 0; s < sc.nSpheres; s++) { // src/bvh.cpp:354-355
             float ts;
-            if (sphereTest(sc.spheres[s], o, d, t, ts))
+            DevSphere sp = sc.spheres[s];
+            if (MOTION) { // src/extra.cpp:149-161
+                const f3 c = moved(mv, ld3(sp.center));
+                sp.center[0] = c.x, sp.center[1] = c.y, sp.center[2] = c.z;
+            }
+            if (sphereTest(sp, o, d, t, ts))
                 t = ts, hit = true;
         }
         const bool visible = !hit || fabsf(t - a.w) <= 0.0001f;
@@ -1558,8 +1572,12 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, bool motion, int p
         (void)hipEventRecord(marks[2], stream);
     if (transp) // (otherwise the samples were shaded when they were generated)
         hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
-    else if (!motion && ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr)
-        hipLaunchKernelGGL(shadowRedoKernel, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr);
+    else if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr) {
+        if (motion)
+            hipLaunchKernelGGL(shadowRedoKernel<true>, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr, ft.movement);
+        else
+            hipLaunchKernelGGL(shadowRedoKernel<false>, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr, 0.0f);
+    }
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
     const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
     if (transp)
@@ -1598,7 +1616,7 @@ hipError_t launchWavefrontGlossy(bool dof, bool stats, int treeBlocks, int shado
     if (marks)
         (void)hipEventRecord(marks[2], stream);
     if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr)
-        hipLaunchKernelGGL(shadowRedoKernel, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr);
+        hipLaunchKernelGGL(shadowRedoKernel<false>, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr, 0.0f);
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
     const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
     hipLaunchKernelGGL(combineKernel<2>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
