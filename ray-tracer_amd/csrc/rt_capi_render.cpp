@@ -162,11 +162,11 @@ size_t traversalLds(const rt_ctx* ctx)
 namespace {
 
 // Motion blur on the queue-based renderer: every (pixel, time sample) pair takes a pixel's place in the queues
-// (rt_wavefront.hpp).  Together with transparency or glossy reflections, or without a single time sample (0 / 0 in every
-// pixel, src/extra.cpp:208), the per-pixel kernel renders it.
+// (rt_wavefront.hpp).  Together with glossy reflections, or without a single time sample (0 / 0 in every pixel,
+// src/extra.cpp:208), the per-pixel kernel renders it.
 static bool motionOnQueues(const rt_features& F)
 {
-    return motionBlurOn(F) && F.motionBlurSamples > 0 && !F.enableTransparency && !(F.enableGlossyReflection && F.enableReflections);
+    return motionBlurOn(F) && F.motionBlurSamples > 0 && !(F.enableGlossyReflection && F.enableReflections);
 }
 
 static int perPixelVariant(const rt_features& F, bool collect)

@@ -1145,8 +1145,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(S
 // the same distance): testVisibilityLightSampleTransparency (src/light.cpp:112-151) once more, every
 // intersect call replayed in the reference's own order of tests.  Leaves the tinted light and the
 // visibility flag where the traversal kernel would have, and counts the rays that went on through a surface.
+// MOTION: in the copy of the scene moved to the sample's time (its ray's record carries it).
+template <bool MOTION>
 __device__ __attribute__((noinline)) void redoTransparentSample(const DevScene& sc, const WfParams& wp, const WfBuffers& wb, DevCounters* ctr,
-    uint32_t item, LdsWords stk, uint32_t stride)
+    uint32_t item, LdsWords stk, uint32_t stride, float movement)
 {
     float4* sr = wb.srays + 3u * (size_t)item;
     const float4 a = sr[0], b = sr[1];
@@ -1159,13 +1161,21 @@ __device__ __attribute__((noinline)) void redoTransparentSample(const DevScene& 
     f3 curKd = ld3(wb.nodeB[node].mkd); // src/light.cpp:126
     float tprod = 1.0f;
     unsigned long long extra = 0;
+    Mover mv;
+    if (MOTION)
+        mv = makeMover(b.w, movement);
     for (;;) {
-        const uint2 res = replayReference(sc.refNodes, sc.tris, stk, stride, o.x, o.y, o.z, d.x, d.y, d.z, tmax);
+        const uint2 res = replayReference<MOTION>(sc.refNodes, sc.tris, stk, stride, o.x, o.y, o.z, d.x, d.y, d.z, tmax, MOTION ? &mv : nullptr);
         float t = __uint_as_float(res.x);
         int prim = (int)res.y;
         for (int k = 0; k < sc.nSpheres; k++) { // src/bvh.cpp:354-355
             float ts;
-            if (sphereTest(sc.spheres[k], o, d, t, ts)) {
+            DevSphere sp = sc.spheres[k];
+            if (MOTION) { // src/extra.cpp:149-161
+                const f3 c = moved(mv, ld3(sp.center));
+                sp.center[0] = c.x, sp.center[1] = c.y, sp.center[2] = c.z;
+            }
+            if (sphereTest(sp, o, d, t, ts)) {
                 t = ts;
                 prim = -2 - k;
             }
@@ -1238,6 +1248,7 @@ __global__ __launch_bounds__(256) void shadowRedoKernel(const DevScene sc, const
     }
 }
 
+template <bool MOTION = false>
 __global__ __launch_bounds__(256) void shadowShadeKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr)
 {
@@ -1246,7 +1257,7 @@ __global__ __launch_bounds__(256) void shadowShadeKernel(const DevScene sc, cons
     const uint32_t total = nNodes * wp.slots;
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
         if (wb.svis[item] == 2)
-            redoTransparentSample(sc, wp, wb, ctr, item, (LdsWords)(redoStack + threadIdx.x), 256u);
+            redoTransparentSample<MOTION>(sc, wp, wb, ctr, item, (LdsWords)(redoStack + threadIdx.x), 256u, ft.movement);
         f3 c = { 0.0f, 0.0f, 0.0f };
         const float4* sr = wb.srays + 3u * (size_t)item;
         const float4 col = sr[2];
@@ -1503,7 +1514,9 @@ typedef void (*ShadowFn)(const DevScene, const DevFeat, const WfParams, const Wf
 
 static ShadowFn pathVariant(bool stats, bool transp, bool motion = false)
 {
-    if (motion) // (without transparency: together they stay with the per-pixel kernel)
+    if (motion && transp)
+        return stats ? pathKernel<true, true, true> : pathKernel<false, true, true>;
+    if (motion)
         return stats ? pathKernel<true, false, true> : pathKernel<false, false, true>;
     if (transp)
         return stats ? pathKernel<true, true> : pathKernel<false, true>;
@@ -1511,6 +1524,8 @@ static ShadowFn pathVariant(bool stats, bool transp, bool motion = false)
 }
 static ShadowFn shadowVariant(bool stats, bool transp, bool motion = false)
 {
+    if (motion && transp)
+        return stats ? shadowTraceKernel<true, true, true> : shadowTraceKernel<false, true, true>;
     if (motion)
         return stats ? shadowTraceKernel<true, false, true> : shadowTraceKernel<false, false, true>;
     if (transp)
@@ -1570,8 +1585,10 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, bool motion, int p
     hipLaunchKernelGGL(shadowVariant(stats, transp, motion), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
     if (marks)
         (void)hipEventRecord(marks[2], stream);
-    if (transp) // (otherwise the samples were shaded when they were generated)
-        hipLaunchKernelGGL(shadowShadeKernel, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
+    if (transp && motion) // (without transparency the samples were shaded when they were generated)
+        hipLaunchKernelGGL(shadowShadeKernel<true>, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
+    else if (transp)
+        hipLaunchKernelGGL(shadowShadeKernel<false>, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
     else if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr) {
         if (motion)
             hipLaunchKernelGGL(shadowRedoKernel<true>, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr, ft.movement);

@@ -133,18 +133,21 @@ def test_motion_blur_corner_cases(ctx):
 
 
 def test_motion_blur_on_the_queue_based_renderer():
-    """Motion blur without transparency or glossy reflections runs on the queue-based renderer: every (pixel, time
-    sample) pair takes a pixel's place in the queues, its rays carry the pair's time and meet the scene moved to it, and
-    the combine takes the mean over a pixel's pairs.  Bit for bit against the per-pixel kernel (which the tests above
-    hold against the oracle, as they do the default renderer): one camera ray per sample and several, mirror chains,
-    all three kinds of light, an environment map, spheres, pixel batches (a small workspace), the counting kernels,
-    shards, and the entry point that allocates nothing."""
+    """Motion blur without glossy reflections runs on the queue-based renderer: every (pixel, time sample) pair takes
+    a pixel's place in the queues, its rays carry the pair's time and meet the scene moved to it, and the combine takes
+    the mean over a pixel's pairs.  Bit for bit against the per-pixel kernel (which the tests above hold against the
+    oracle, as they do the default renderer): one camera ray per sample and several, mirror chains, transparency, all
+    three kinds of light, an environment map, spheres, pixel batches (a small workspace), the counting kernels, shards,
+    and the entry point that allocates nothing."""
     import copy
     import torch
     scn = copy.deepcopy(common.scene("CornellBox", env_map=True))
     scn.lights = [sio.cornell_parallelogram_light(), sio.point_light((0.2, 0.3, 0.4), (0.6, 0.5, 0.4)),
                   sio.segment_light((-0.3, 0.4, -0.2), (0.3, 0.4, 0.2), (1, 0, 0), (0, 0, 1))]
     spheres = sio.load_scene_prebuilt("Spheres", common.DATA)
+    clear = copy.deepcopy(scn)
+    for i, m in enumerate(clear.meshes):
+        m.material["transparency"] = 1.0 if i == 0 else 0.55  # (one mesh stays opaque)
     w, h = 45, 27  # (partial tiles on both edges)
     cases = [
         (scn, sio.default_camera(w, h), dict(motionBlurSamples=1, movement=0.5, numShadowSamples=1)),
@@ -156,18 +159,28 @@ def test_motion_blur_on_the_queue_based_renderer():
                                              enableShadows=0)),
         (spheres, sio.default_camera(w, h, distance=6.0, look_at=(0, 0, 12), rotation_deg=(0, 180, 0)),
          dict(motionBlurSamples=4, movement=0.5, numShadowSamples=1, enableReflections=1)),
+        # pass-through rays and light tinted on its way through surfaces, in the moved copy
+        (clear, sio.default_camera(w, h), dict(motionBlurSamples=3, movement=0.6, numShadowSamples=2, enableTransparency=1,
+                                               enableReflections=1, maxRayDepth=3, numPixelSamples=2)),
+        (clear, sio.default_camera(w, h), dict(motionBlurSamples=2, movement=0.4, numShadowSamples=1, enableTransparency=1,
+                                               enableEnvironmentMap=1, maxRayDepth=4)),
     ]
+    batched = {False: [], True: []}  # pixel batches of the small-workspace frames, without and with transparency
     for k, (s, cam, kw) in enumerate(cases):
         kw = dict(dict(enableShading=1, enableShadows=1, shadingModel=2, enableNormalInterp=1), **kw)
         f = common.features(enableMotionBlur=1, **kw)
         images, rays = {}, {}
-        for name, opts in (("queues", dict(per_pixel=0)), ("queues, small workspace", dict(per_pixel=0, workspace_bytes=2 << 20)),
+        # (a workspace that makes several pixel batches of the frame; a tree of hits under transparency takes more per tile)
+        small = (8 << 20) if kw.get("enableTransparency") else (2 << 20)
+        for name, opts in (("queues", dict(per_pixel=0)), ("queues, small workspace", dict(per_pixel=0, workspace_bytes=small)),
                            ("per pixel", dict(per_pixel=1))):
             c = capi.Context(0, **opts)
             c.upload_scene(s)
             c.set_features(f)
             images[name], st = c.render(cam, w, h)
             rays[name] = st["rays"]
+            if name == "queues, small workspace":
+                batched[bool(kw.get("enableTransparency"))].append(st["batches"])
             if name == "queues":  # the counting kernels, packed shards, and the static scratch
                 buf = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
                 st2 = c.render_device(cam, w, h, buf.data_ptr(), buf.numel(), 0, 1, 0, collect_stats=True)
@@ -183,6 +196,7 @@ def test_motion_blur_on_the_queue_based_renderer():
         for name in images:
             assert np.array_equal(images[name].view(np.uint32), images["per pixel"].view(np.uint32)), \
                 (k, name, common.image_error(images[name], images["per pixel"]))
+    assert max(batched[False]) > 1 and max(batched[True]) > 1, batched
     # shards of the frame, packed
     s, cam, kw = cases[2]
     f = common.features(enableMotionBlur=1, enableShading=1, enableShadows=1, shadingModel=2, **kw)
