@@ -162,11 +162,12 @@ size_t traversalLds(const rt_ctx* ctx)
 namespace {
 
 // Motion blur on the queue-based renderer: every (pixel, time sample) pair takes a pixel's place in the queues
-// (rt_wavefront.hpp).  Together with glossy reflections, or without a single time sample (0 / 0 in every pixel,
-// src/extra.cpp:208), the per-pixel kernel renders it.
+// (rt_wavefront.hpp).  Without a single time sample (0 / 0 in every pixel, src/extra.cpp:208) the per-pixel kernel
+// renders it, and whatever else keeps a frame from the queues (glossy reflections together with transparency) does so
+// with motion blur too.
 static bool motionOnQueues(const rt_features& F)
 {
-    return motionBlurOn(F) && F.motionBlurSamples > 0 && !(F.enableGlossyReflection && F.enableReflections);
+    return motionBlurOn(F) && F.motionBlurSamples > 0;
 }
 
 static int perPixelVariant(const rt_features& F, bool collect)
@@ -420,7 +421,7 @@ static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const 
     else
         HIP_TRY(ctx, wavefrontOccupancy(collect, q.transp, motionWf, kBlockThreads, lds, &pathPerCU, &shadowPerCU));
     if (glossyWf) // (the tree kernel stands in the path kernel's place; asking is no allocation)
-        HIP_TRY(ctx, glossyOccupancy(q.dof, collect, kBlockThreads, lds, &pathPerCU));
+        HIP_TRY(ctx, glossyOccupancy(q.dof, collect, motionWf, kBlockThreads, lds, &pathPerCU));
     if (pathPerCU < 1 || shadowPerCU < 1)
         return fail(ctx, RT_ERR_DEVICE, "render: the traversing kernels do not fit a compute unit (%zu B of LDS)", lds);
     pathPerCU = std::min(pathPerCU, kMaxBlocksPerCU), shadowPerCU = std::min(shadowPerCU, kMaxBlocksPerCU);
@@ -694,7 +695,7 @@ static int launchBatches(rt_ctx* ctx, QueueFrame& q, const WfBuffers& wb, const 
             ctx->marksUsed += 4;
         }
         if (q.glossy)
-            HIP_TRY(ctx, launchWavefrontGlossy(q.dof, collect, q.pathBlocks, q.shadowBlocks, kBlockThreads, lds, stream, ctx->scene, cam, ft, fr,
+            HIP_TRY(ctx, launchWavefrontGlossy(q.dof, collect, q.motion, q.pathBlocks, q.shadowBlocks, kBlockThreads, lds, stream, ctx->scene, cam, ft, fr,
                               wp, wb, dCounters, dOut, pathKnobs, shadowKnobs, marks, ctx->numCU));
         else
             HIP_TRY(ctx, launchWavefront(q.dof, collect, q.transp, q.motion, q.pathBlocks, q.shadowBlocks, kBlockThreads, lds, stream, ctx->scene, cam, ft,
@@ -765,8 +766,8 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     // else is shared with the mirror case), except together with transparency, which only the per-pixel kernel combines.
     // So does motion blur (motionOnQueues).
     const bool glossyOn = F.enableGlossyReflection && F.enableReflections;
-    const bool glossyWf = glossyOn && !ctx->forcePerPixel && !F.enableTransparency && !motionBlurOn(F);
-    const bool motionWf = motionOnQueues(F) && !ctx->forcePerPixel;
+    const bool glossyWf = glossyOn && !ctx->forcePerPixel && !F.enableTransparency && (!motionBlurOn(F) || motionOnQueues(F));
+    const bool motionWf = motionOnQueues(F) && !ctx->forcePerPixel && (!glossyOn || glossyWf);
     const bool perPixel = ctx->forcePerPixel || (glossyOn && !glossyWf) || (motionBlurOn(F) && !motionWf);
     int rc = RT_OK;
     if (perPixel) {

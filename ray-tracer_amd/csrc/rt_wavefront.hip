@@ -530,14 +530,17 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
 //     and the sums are left to the coherent kernels below, as for mirror reflections.
 //     Frames of a lane's walk (the hits that still have children to come) sit in LDS, one per depth.
 // ---------------------------------------------------------------------------
-template <bool DOF, bool STATS>
+//     MOTION: the work items are the batch's sample slots, (pixel slot, time sample) pairs, each walked like a pixel
+//     with the pair's own stretch of the stream, every ray in the copy of the scene moved to the pair's time.
+template <bool DOF, bool STATS, bool MOTION = false>
 __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene sc, const DevCamera cam,
     const DevFeat ft, const DevFrame fr, const WfParams wp, const WfBuffers wb, DevCounters* __restrict__ ctr, int minActive)
 {
     extern __shared__ uint32_t stackMem[];
-    const Tracer<STATS> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
+    const Tracer<STATS, MOTION> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = wp.nSlots; // work items are the batch's pixel slots
+    const uint32_t M = MOTION ? (uint32_t)ft.motionSamples : 1u;
+    const uint32_t total = wp.nSlots * M; // work items are the batch's pixel slots (MOTION: sample slots)
     uint32_t nodeBlock = wp.nodeBlockMax;
     while (wp.nodeBlockFixed == 0u && nodeBlock > 64u && nodeBlock * (gridDim.x * (blockDim.x / 64u)) > 2u * total * wp.R)
         nodeBlock >>= 1;
@@ -635,8 +638,13 @@ __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene
             bool want = !have && !dead;
             q.fetch(want, item, dead, &ctr->next, &ctr->dry[0], total, lane);
             if (!have && !dead && !want) {
-                if (slotToPixel(fr, wp.slotBegin + item, px, py)) { // (padding pixels of partial edge tiles have no rays)
-                    const uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
+                const uint32_t pslot = MOTION ? item / M : item;
+                if (slotToPixel(fr, wp.slotBegin + pslot, px, py)) { // (padding pixels of partial edge tiles have no rays)
+                    uint32_t seed = (uint32_t)(fr.height * px + py); // src/render.cpp:38
+                    if (MOTION) { // the pair's time is draw m + 1 of the pixel's stream; the pair has the stream from there (src/extra.cpp:145-204)
+                        seed = lcgSkip(seed, item - pslot * M);
+                        r.mv = makeMover(next1d(seed), ft.movement);
+                    }
                     sPix = seed;
                     sLens = ft.lensMul * seed + ft.lensAdd;
                     sMain = ft.mainMul * seed + ft.mainAdd;
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene
                         }
                     }
                 } else {
-                    const HitCtx h = shadeHit(sc, ft, r);
+                    const HitCtx h = shadeHit<MOTION>(sc, ft, r);
                     const uint32_t idx = allocNode();
                     if (idx < wb.maxNodes) { // always: the pool holds the worst case of the batch
                         made++;
@@ -1605,35 +1613,41 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, bool motion, int p
 }
 
 typedef void (*GlossyFn)(const DevScene, const DevCamera, const DevFeat, const DevFrame, const WfParams, const WfBuffers, DevCounters*, int);
-static GlossyFn glossyVariant(bool dof, bool stats)
+static GlossyFn glossyVariant(bool dof, bool stats, bool motion = false)
 {
+    if (motion) // (depth of field takes the frame when both are asked for)
+        return stats ? glossyTreeKernel<false, true, true> : glossyTreeKernel<false, false, true>;
     if (dof)
         return stats ? glossyTreeKernel<true, true> : glossyTreeKernel<true, false>;
     return stats ? glossyTreeKernel<false, true> : glossyTreeKernel<false, false>;
 }
 
-hipError_t glossyOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* treeBlocks)
+hipError_t glossyOccupancy(bool dof, bool stats, bool motion, int blockThreads, size_t ldsBytes, int* treeBlocks)
 {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(treeBlocks, glossyVariant(dof, stats), blockThreads, ldsBytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(treeBlocks, glossyVariant(dof, stats, motion), blockThreads, ldsBytes);
 }
 
 // The frame with glossy reflections: the tree kernel writes every pixel's hits down, the light samples of all
 // hits are generated, traced and shaded as for mirror reflections, the combine folds the trees.
-hipError_t launchWavefrontGlossy(bool dof, bool stats, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
+hipError_t launchWavefrontGlossy(bool dof, bool stats, bool motion, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
     const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp, const WfBuffers& wb, DevCounters* ctr,
     float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU)
 {
-    hipLaunchKernelGGL(glossyVariant(dof, stats), dim3(treeBlocks), dim3(blockThreads), ldsBytes, stream, sc, cam, ft, fr, wp, wb, ctr, minActive);
+    hipLaunchKernelGGL(glossyVariant(dof, stats, motion), dim3(treeBlocks), dim3(blockThreads), ldsBytes, stream, sc, cam, ft, fr, wp, wb, ctr, minActive);
     if (marks)
         (void)hipEventRecord(marks[0], stream);
     hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * RT_GEN_BLOCKS), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr, sc.lights);
     if (marks)
         (void)hipEventRecord(marks[1], stream);
-    hipLaunchKernelGGL(shadowVariant(stats, false), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
+    hipLaunchKernelGGL(shadowVariant(stats, false, motion), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
     if (marks)
         (void)hipEventRecord(marks[2], stream);
-    if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr)
-        hipLaunchKernelGGL(shadowRedoKernel<false>, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr, 0.0f);
+    if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr) {
+        if (motion)
+            hipLaunchKernelGGL(shadowRedoKernel<true>, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr, ft.movement);
+        else
+            hipLaunchKernelGGL(shadowRedoKernel<false>, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr, 0.0f);
+    }
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
     const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
     hipLaunchKernelGGL(combineKernel<2>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);

@@ -75,8 +75,8 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, bool motion, int p
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
     const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
 
-hipError_t glossyOccupancy(bool dof, bool stats, int blockThreads, size_t ldsBytes, int* treeBlocks);
-hipError_t launchWavefrontGlossy(bool dof, bool stats, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
+hipError_t glossyOccupancy(bool dof, bool stats, bool motion, int blockThreads, size_t ldsBytes, int* treeBlocks);
+hipError_t launchWavefrontGlossy(bool dof, bool stats, bool motion, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
     const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp, const WfBuffers& wb, DevCounters* ctr,
     float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
 

@@ -133,12 +133,12 @@ def test_motion_blur_corner_cases(ctx):
 
 
 def test_motion_blur_on_the_queue_based_renderer():
-    """Motion blur without glossy reflections runs on the queue-based renderer: every (pixel, time sample) pair takes
-    a pixel's place in the queues, its rays carry the pair's time and meet the scene moved to it, and the combine takes
-    the mean over a pixel's pairs.  Bit for bit against the per-pixel kernel (which the tests above hold against the
-    oracle, as they do the default renderer): one camera ray per sample and several, mirror chains, transparency, all
-    three kinds of light, an environment map, spheres, pixel batches (a small workspace), the counting kernels, shards,
-    and the entry point that allocates nothing."""
+    """Motion blur runs on the queue-based renderer: every (pixel, time sample) pair takes a pixel's place in the
+    queues, its rays carry the pair's time and meet the scene moved to it, and the combine takes the mean over a
+    pixel's pairs.  Bit for bit against the per-pixel kernel (which the tests above hold against the oracle, as they
+    do the default renderer): one camera ray per sample and several, mirror chains, transparency, glossy reflections,
+    all three kinds of light, an environment map, spheres, pixel batches (a small workspace), the counting kernels,
+    shards, and the entry point that allocates nothing."""
     import copy
     import torch
     scn = copy.deepcopy(common.scene("CornellBox", env_map=True))
@@ -164,6 +164,12 @@ def test_motion_blur_on_the_queue_based_renderer():
                                                enableReflections=1, maxRayDepth=3, numPixelSamples=2)),
         (clear, sio.default_camera(w, h), dict(motionBlurSamples=2, movement=0.4, numShadowSamples=1, enableTransparency=1,
                                                enableEnvironmentMap=1, maxRayDepth=4)),
+        # glossy reflections: the tree kernel walks every (pixel, time sample) pair
+        (scn, sio.default_camera(w, h), dict(motionBlurSamples=3, movement=0.5, numShadowSamples=2, enableReflections=1, maxRayDepth=2,
+                                             enableGlossyReflection=1, numGlossySamples=3, glossyExponent=0.5, numPixelSamples=2,
+                                             enableEnvironmentMap=1)),
+        (scn, sio.default_camera(w, h), dict(motionBlurSamples=2, movement=0.9, numShadowSamples=1, enableReflections=1, maxRayDepth=3,
+                                             enableGlossyReflection=1, numGlossySamples=2, glossyExponent=1.0)),
     ]
     batched = {False: [], True: []}  # pixel batches of the small-workspace frames, without and with transparency
     for k, (s, cam, kw) in enumerate(cases):
