@@ -163,8 +163,7 @@ namespace {
 
 // Motion blur on the queue-based renderer: every (pixel, time sample) pair takes a pixel's place in the queues
 // (rt_wavefront.hpp).  Without a single time sample (0 / 0 in every pixel, src/extra.cpp:208) the per-pixel kernel
-// renders it, and whatever else keeps a frame from the queues (glossy reflections together with transparency) does so
-// with motion blur too.
+// renders it.
 static bool motionOnQueues(const rt_features& F)
 {
     return motionBlurOn(F) && F.motionBlurSamples > 0;
@@ -421,7 +420,7 @@ static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const 
     else
         HIP_TRY(ctx, wavefrontOccupancy(collect, q.transp, motionWf, kBlockThreads, lds, &pathPerCU, &shadowPerCU));
     if (glossyWf) // (the tree kernel stands in the path kernel's place; asking is no allocation)
-        HIP_TRY(ctx, glossyOccupancy(q.dof, collect, motionWf, kBlockThreads, lds, &pathPerCU));
+        HIP_TRY(ctx, glossyOccupancy(q.dof, collect, motionWf, q.transp, kBlockThreads, lds, &pathPerCU));
     if (pathPerCU < 1 || shadowPerCU < 1)
         return fail(ctx, RT_ERR_DEVICE, "render: the traversing kernels do not fit a compute unit (%zu B of LDS)", lds);
     pathPerCU = std::min(pathPerCU, kMaxBlocksPerCU), shadowPerCU = std::min(shadowPerCU, kMaxBlocksPerCU);
@@ -479,14 +478,14 @@ static int queueFrame(rt_ctx* ctx, const DevFeat& ft, const DevFrame& fr, const 
     const bool mirrors = F.enableReflections && ctx->anyMirror, passes = q.transp && ctx->anyClear;
     uint64_t nodesPerPath = 1;
     if (glossyWf) {
-        // every hit below the depth cap fans out into numGlossySamples children (src/extra.cpp:348-362), each a hit or,
-        // with an environment map, a node that carries the colour it left the scene with
-        if (mirrors) {
-            uint64_t level = 1;
-            for (int d = 0; d < F.maxRayDepth && nodesPerPath < (1ull << 40); d++) {
-                level *= std::max<uint64_t>(1, F.numGlossySamples);
-                nodesPerPath += F.numGlossySamples ? level : 0;
-            }
+        // every hit below the depth cap fans out into numGlossySamples children (src/extra.cpp:348-362) and, on a material
+        // that is not opaque, a pass-through child, each a hit or, with an environment map, a node that carries the
+        // colour it left the scene with
+        const uint64_t fan = (mirrors ? F.numGlossySamples : 0u) + (passes ? 1u : 0u);
+        uint64_t level = 1;
+        for (int d = 0; d < F.maxRayDepth && level != 0 && nodesPerPath < (1ull << 40); d++) {
+            level *= fan;
+            nodesPerPath += level;
         }
     } else if (mirrors && passes && ctx->anyMirrorAndClear)
         nodesPerPath = (2ull << F.maxRayDepth) - 1;
@@ -695,7 +694,7 @@ static int launchBatches(rt_ctx* ctx, QueueFrame& q, const WfBuffers& wb, const 
             ctx->marksUsed += 4;
         }
         if (q.glossy)
-            HIP_TRY(ctx, launchWavefrontGlossy(q.dof, collect, q.motion, q.pathBlocks, q.shadowBlocks, kBlockThreads, lds, stream, ctx->scene, cam, ft, fr,
+            HIP_TRY(ctx, launchWavefrontGlossy(q.dof, collect, q.motion, q.transp, q.pathBlocks, q.shadowBlocks, kBlockThreads, lds, stream, ctx->scene, cam, ft, fr,
                               wp, wb, dCounters, dOut, pathKnobs, shadowKnobs, marks, ctx->numCU));
         else
             HIP_TRY(ctx, launchWavefront(q.dof, collect, q.transp, q.motion, q.pathBlocks, q.shadowBlocks, kBlockThreads, lds, stream, ctx->scene, cam, ft,
@@ -763,10 +762,9 @@ static int renderCommon(rt_ctx* ctx, const rt_camera* camera, int width, int hei
     if (arena && !occReady)
         return fail(ctx, RT_ERR_STATE, "render: launch geometry not prepared (rt_scene_upload and rt_features_set do that)");
     // Glossy reflections take the queue-based renderer too (a tree kernel walks each pixel's radiance rays, everything
-    // else is shared with the mirror case), except together with transparency, which only the per-pixel kernel combines.
-    // So does motion blur (motionOnQueues).
+    // else is shared with the mirror case).  So does motion blur (motionOnQueues).
     const bool glossyOn = F.enableGlossyReflection && F.enableReflections;
-    const bool glossyWf = glossyOn && !ctx->forcePerPixel && !F.enableTransparency && (!motionBlurOn(F) || motionOnQueues(F));
+    const bool glossyWf = glossyOn && !ctx->forcePerPixel && (!motionBlurOn(F) || motionOnQueues(F));
     const bool motionWf = motionOnQueues(F) && !ctx->forcePerPixel && (!glossyOn || glossyWf);
     const bool perPixel = ctx->forcePerPixel || (glossyOn && !glossyWf) || (motionBlurOn(F) && !motionWf);
     int rc = RT_OK;

@@ -532,7 +532,13 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
 // ---------------------------------------------------------------------------
 //     MOTION: the work items are the batch's sample slots, (pixel slot, time sample) pairs, each walked like a pixel
 //     with the pair's own stretch of the stream, every ray in the copy of the scene moved to the pair's time.
-template <bool DOF, bool STATS, bool MOTION = false>
+//     TRANSP: a hit on a material that is not opaque also has a pass-through child, traced after its glossy children
+//     (src/recursive.cpp:48-60) and linked through NodeB::pad: a node index, kChildNone (none wanted) or kChildMiss
+//     (it left the scene without a colour).
+constexpr uint32_t kFrameCount = 0x0fffffffu;   // TRANSP, frameDone: glossy children done ...
+constexpr uint32_t kFramePassWanted = 1u << 31; // ... the hit wants a pass-through child ...
+constexpr uint32_t kFramePassFlying = 1u << 30; // ... and that child is the ray under way (the glossy children are done)
+template <bool DOF, bool STATS, bool MOTION = false, bool TRANSP = false>
 __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene sc, const DevCamera cam,
     const DevFeat ft, const DevFrame fr, const WfParams wp, const WfBuffers wb, DevCounters* __restrict__ ctr, int minActive)
 {
@@ -600,6 +606,10 @@ __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene
     // the node just made becomes the next child of the innermost open hit
     auto linkChild = [&](uint32_t idx) {
         const uint32_t top = kBlockThreads * (uint32_t)(sp - 1);
+        if (TRANSP && (frameDone[top] & kFramePassFlying)) {
+            wb.nodeB[frameNode[top]].pad = idx;
+            return;
+        }
         const uint32_t last = frameLast[top];
         if (last == (uint32_t)kChildNone)
             wb.nodeB[frameNode[top]].childR = (int32_t)idx;
@@ -630,6 +640,15 @@ __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene
         const f3 sV = v * rr * sinLikeHost(theta);
         const f3 dir = normalize(R + sU + sV);
         tracer.launch(r, P + dir * 1.0e-5f, dir, kFltMax, K_RADIANCE);
+        nrays++;
+    };
+    // the pass-through ray of the innermost open hit (generatePassthroughRay, src/recursive.cpp:98-111), likewise
+    auto spawnPass = [&]() {
+        const uint32_t n = frameNode[kBlockThreads * (uint32_t)(sp - 1)];
+        const float4* a = wb.nodeA + 4u * (size_t)n;
+        const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+        const f3 P = { a0.x, a0.y, a0.z }, rd = { a1.z, a1.w, a2.x };
+        tracer.launch(r, P + rd * 1.0e-5f, rd, kFltMax, K_RADIANCE);
         nrays++;
     };
 
@@ -683,9 +702,12 @@ __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene
                             wb.pathEnv[3u * path + 1] = env.y;
                             wb.pathEnv[3u * path + 2] = env.z;
                         }
+                    } else if (TRANSP && !ft.envMap && (frameDone[kBlockThreads * (uint32_t)(sp - 1)] & kFramePassFlying)) {
+                        // a pass-through child that left the scene: its (black) value is still blended with the hit's
+                        wb.nodeB[frameNode[kBlockThreads * (uint32_t)(sp - 1)]].pad = (uint32_t)kChildMiss;
                     } else if (ft.envMap) {
                         // a child that left the scene with a colour of its own: a node without a hit, which carries the
-                        // colour (without an environment map such a child adds exactly zero and is left out)
+                        // colour (without an environment map such a glossy child adds exactly zero and is left out)
                         const f3 env = sampleEnvironmentMap(sc, ft, r.d);
                         const uint32_t idx = allocNode();
                         if (idx < wb.maxNodes) {
@@ -716,6 +738,8 @@ __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene
                         nb.childR = nb.childP = kChildNone;
                         nb.tr = h.tr;
                         nb.mkd[0] = h.mkd.x, nb.mkd[1] = h.mkd.y, nb.mkd[2] = h.mkd.z;
+                        if (TRANSP)
+                            nb.pad = (uint32_t)kChildNone;
                         wb.nodeB[idx] = nb;
                         if (sp == 0)
                             wb.pathHead[path] = (int32_t)idx;
@@ -725,13 +749,18 @@ __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene
                         draws += wp.drawsPerHit;
                         sMain = lcgSkip(sMain, wp.drawsPerHit);
                         const bool reflective = !(h.ks.x == 0.0f && h.ks.y == 0.0f && h.ks.z == 0.0f);
-                        if (sp < ft.maxDepth && ft.reflections && reflective && (int)g > 0) {
+                        const bool fan = ft.reflections && reflective && (int)g > 0;
+                        const bool pass = TRANSP && ft.transparency && h.tr != 1.0f;
+                        if (sp < ft.maxDepth && (fan || pass)) {
                             const uint32_t top = kBlockThreads * (uint32_t)sp;
                             frameNode[top] = idx;
-                            frameDone[top] = 0u;
+                            frameDone[top] = TRANSP ? ((pass ? kFramePassWanted : 0u) | (fan ? 0u : kFramePassFlying)) : 0u;
                             frameLast[top] = (uint32_t)kChildNone;
                             sp++;
-                            spawnChild();
+                            if (fan)
+                                spawnChild();
+                            else
+                                spawnPass();
                             spawned = true;
                         }
                     } else {
@@ -749,6 +778,26 @@ __global__ __launch_bounds__(kBlockThreads) void glossyTreeKernel(const DevScene
                             break;
                         }
                         const uint32_t top = kBlockThreads * (uint32_t)(sp - 1);
+                        if (TRANSP) {
+                            const uint32_t st = frameDone[top];
+                            if (st & kFramePassFlying) { // the pass-through child was the hit's last
+                                sp--;
+                                continue;
+                            }
+                            const uint32_t done = (st & kFrameCount) + 1u;
+                            if (done < g) {
+                                frameDone[top] = (st & ~kFrameCount) | done;
+                                spawnChild();
+                                break;
+                            }
+                            if (st & kFramePassWanted) {
+                                frameDone[top] = st | kFramePassFlying;
+                                spawnPass();
+                                break;
+                            }
+                            sp--;
+                            continue;
+                        }
                         const uint32_t done = frameDone[top] + 1u;
                         frameDone[top] = done;
                         if (done < g) {
@@ -1460,10 +1509,92 @@ __device__ __forceinline__ f3 pathValueGlossy(const DevScene& sc, const DevFeat&
     }
 }
 
+// The same with transparency on top: the hit's value so far is blended with its pass-through child's
+// (src/recursive.cpp:142), which NodeB::pad names: a node (a hit, or one that carries the colour the ray left the
+// scene with), kChildMiss (it left without a colour) or kChildNone (the material is opaque, or the depth cap).
+__device__ __forceinline__ f3 pathValueGlossyClear(const DevScene& sc, const DevFeat& ft, const WfParams& wp, const WfBuffers& wb, uint32_t path)
+{
+    const int32_t head = wb.pathHead[path];
+    if (head == kPathMiss)
+        return ft.envMap ? ld3(wb.pathEnv + 3u * path) : mk3(0.0f);
+    int32_t nodeAt[kMaxDepth + 1], child[kMaxDepth + 1];
+    int stage[kMaxDepth + 1]; // 1 glossy children under way, 2 pass-through child under way
+    f3 Lo[kMaxDepth + 1], acc[kMaxDepth + 1]; // Lo: the hit's own light; in stage 2 its value before the blend
+    int sp = 0;
+    nodeAt[0] = head;
+    bool entering = true;
+    f3 ret = mk3(0.0f);
+    for (;;) {
+        const uint32_t n = (uint32_t)nodeAt[sp];
+        const NodeB& nb = wb.nodeB[n];
+        bool fanStage = false, closed = false;
+        int32_t next = kChildNone;
+        f3 val = mk3(0.0f);
+        if (entering) {
+            if (nb.path == kDeadNode) {
+                ret = ld3(nb.cvR);
+                closed = true;
+            } else {
+                Lo[sp] = nodeLo(sc, ft, wb, n, wp.slots);
+                const float4 a3 = wb.nodeA[4u * (size_t)n + 3];
+                const bool reflective = !(a3.x == 0.0f && a3.y == 0.0f && a3.z == 0.0f);
+                if (nb.depth < ft.maxDepth && ft.reflections && reflective) {
+                    acc[sp] = mk3(0.0f);
+                    stage[sp] = 1;
+                    fanStage = true;
+                    next = nb.childR;
+                } else {
+                    val = Lo[sp];
+                }
+            }
+        } else if (stage[sp] == 1) { // a glossy child's value has come back
+            acc[sp] = acc[sp] + ret;
+            fanStage = true;
+            next = wb.nodeB[child[sp]].childP;
+        } else { // the pass-through child's
+            const float tr = nb.tr;
+            ret = (ret * tr) + (Lo[sp] * (1.0f - tr));
+            closed = true;
+        }
+        if (!closed) {
+            if (fanStage) {
+                if (next >= 0 && sp < kMaxDepth) {
+                    child[sp] = next;
+                    sp++;
+                    nodeAt[sp] = next;
+                    entering = true;
+                    continue;
+                }
+                const float4 a3 = wb.nodeA[4u * (size_t)n + 3];
+                val = Lo[sp] + (acc[sp] / (float)(int)ft.glossySamples) * mk3(a3.x, a3.y, a3.z);
+            }
+            const int32_t pc = (int32_t)nb.pad;
+            if (pc >= 0 && sp < kMaxDepth) {
+                Lo[sp] = val;
+                stage[sp] = 2;
+                sp++;
+                nodeAt[sp] = pc;
+                entering = true;
+                continue;
+            }
+            if (pc == kChildMiss) {
+                const float tr = nb.tr;
+                val = (mk3(0.0f) * tr) + (val * (1.0f - tr));
+            }
+            ret = val;
+        }
+        if (sp == 0)
+            return ret;
+        sp--;
+        entering = false;
+    }
+}
+
 // One lane per camera ray evaluates its chain (the chains of a pixel sit all over the node
 // pool, so their latencies overlap instead of queueing up in one lane); the first lane of
 // each pixel then adds the pixel's values in ray order, exactly as renderRays does.
-// MODE 0: chains of mirror hits, 1: trees with pass-through children (transparency), 2: trees of glossy children
+// MODE 0: chains of mirror hits, 1: trees with pass-through children (transparency), 2: trees of glossy children,
+// 3: of glossy and pass-through children
 template <int MODE>
 __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const DevFeat ft, const DevFrame fr, const WfParams wp,
     const WfBuffers wb, float* __restrict__ out)
@@ -1489,8 +1620,9 @@ __global__ __launch_bounds__(256) void combineKernel(const DevScene sc, const De
             const uint32_t i = base + j;
             f3 v = mk3(0.0f);
             if (sees && i < wp.R)
-                v = MODE == 2 ? pathValueGlossy(sc, ft, wp, wb, first + i)
-                    : (MODE == 1 ? pathValueTree(sc, ft, wp, wb, first + i) : pathValue(sc, ft, wp, wb, first + i));
+                v = MODE == 3 ? pathValueGlossyClear(sc, ft, wp, wb, first + i)
+                    : (MODE == 2 ? pathValueGlossy(sc, ft, wp, wb, first + i)
+                        : (MODE == 1 ? pathValueTree(sc, ft, wp, wb, first + i) : pathValue(sc, ft, wp, wb, first + i)));
             vals[3u * threadIdx.x + 0] = v.x;
             vals[3u * threadIdx.x + 1] = v.y;
             vals[3u * threadIdx.x + 2] = v.z;
@@ -1613,8 +1745,15 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, bool motion, int p
 }
 
 typedef void (*GlossyFn)(const DevScene, const DevCamera, const DevFeat, const DevFrame, const WfParams, const WfBuffers, DevCounters*, int);
-static GlossyFn glossyVariant(bool dof, bool stats, bool motion = false)
+static GlossyFn glossyVariant(bool dof, bool stats, bool motion = false, bool transp = false)
 {
+    if (transp) {
+        if (motion)
+            return stats ? glossyTreeKernel<false, true, true, true> : glossyTreeKernel<false, false, true, true>;
+        if (dof)
+            return stats ? glossyTreeKernel<true, true, false, true> : glossyTreeKernel<true, false, false, true>;
+        return stats ? glossyTreeKernel<false, true, false, true> : glossyTreeKernel<false, false, false, true>;
+    }
     if (motion) // (depth of field takes the frame when both are asked for)
         return stats ? glossyTreeKernel<false, true, true> : glossyTreeKernel<false, false, true>;
     if (dof)
@@ -1622,27 +1761,31 @@ static GlossyFn glossyVariant(bool dof, bool stats, bool motion = false)
     return stats ? glossyTreeKernel<false, true> : glossyTreeKernel<false, false>;
 }
 
-hipError_t glossyOccupancy(bool dof, bool stats, bool motion, int blockThreads, size_t ldsBytes, int* treeBlocks)
+hipError_t glossyOccupancy(bool dof, bool stats, bool motion, bool transp, int blockThreads, size_t ldsBytes, int* treeBlocks)
 {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(treeBlocks, glossyVariant(dof, stats, motion), blockThreads, ldsBytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(treeBlocks, glossyVariant(dof, stats, motion, transp), blockThreads, ldsBytes);
 }
 
 // The frame with glossy reflections: the tree kernel writes every pixel's hits down, the light samples of all
 // hits are generated, traced and shaded as for mirror reflections, the combine folds the trees.
-hipError_t launchWavefrontGlossy(bool dof, bool stats, bool motion, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
+hipError_t launchWavefrontGlossy(bool dof, bool stats, bool motion, bool transp, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
     const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp, const WfBuffers& wb, DevCounters* ctr,
     float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU)
 {
-    hipLaunchKernelGGL(glossyVariant(dof, stats, motion), dim3(treeBlocks), dim3(blockThreads), ldsBytes, stream, sc, cam, ft, fr, wp, wb, ctr, minActive);
+    hipLaunchKernelGGL(glossyVariant(dof, stats, motion, transp), dim3(treeBlocks), dim3(blockThreads), ldsBytes, stream, sc, cam, ft, fr, wp, wb, ctr, minActive);
     if (marks)
         (void)hipEventRecord(marks[0], stream);
     hipLaunchKernelGGL(shadowGenKernel, dim3(numCU * RT_GEN_BLOCKS), dim3(256), 0, stream, sc, ft, fr, wp, wb, ctr, sc.lights);
     if (marks)
         (void)hipEventRecord(marks[1], stream);
-    hipLaunchKernelGGL(shadowVariant(stats, false, motion), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
+    hipLaunchKernelGGL(shadowVariant(stats, transp, motion), dim3(shadowBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActiveShadow);
     if (marks)
         (void)hipEventRecord(marks[2], stream);
-    if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr) {
+    if (transp && motion) // (as in launchWavefront)
+        hipLaunchKernelGGL(shadowShadeKernel<true>, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
+    else if (transp)
+        hipLaunchKernelGGL(shadowShadeKernel<false>, dim3(numCU * 8), dim3(256), 0, stream, sc, ft, wp, wb, ctr);
+    else if (ft.shadows && ft.accel && sc.refNodes != nullptr && sc.leafBoxes != nullptr) {
         if (motion)
             hipLaunchKernelGGL(shadowRedoKernel<true>, dim3(numCU), dim3(256), 0, stream, sc, wb, ctr, ft.movement);
         else
@@ -1650,7 +1793,10 @@ hipError_t launchWavefrontGlossy(bool dof, bool stats, bool motion, int treeBloc
     }
     const uint32_t pixelsPerBlock = 256u / (wp.R < 256u ? wp.R : 256u);
     const dim3 combineGrid((wp.nSlots + pixelsPerBlock - 1) / pixelsPerBlock);
-    hipLaunchKernelGGL(combineKernel<2>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
+    if (transp)
+        hipLaunchKernelGGL(combineKernel<3>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
+    else
+        hipLaunchKernelGGL(combineKernel<2>, combineGrid, dim3(256), 0, stream, sc, ft, fr, wp, wb, out);
     return hipGetLastError();
 }
 

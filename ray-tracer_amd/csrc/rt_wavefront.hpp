@@ -22,7 +22,7 @@ struct NodeB {
     float cvP[3];     // (without transparency: the hit's ks, read by the combine)
     float tr;         // material transparency
     float mkd[3];     // material kd (not the texture's): where the transparent shadow test starts, src/light.cpp:126
-    uint32_t pad;
+    uint32_t pad;     // (glossy reflections with transparency: the pass-through child, as childR / childP elsewhere)
 };
 static_assert(sizeof(NodeB) == 64, "NodeB is one 64-B record");
 constexpr int32_t kChildNone = -1, kChildMiss = -2;
@@ -75,8 +75,8 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, bool motion, int p
     hipStream_t stream, const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp,
     const WfBuffers& wb, DevCounters* ctr, float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
 
-hipError_t glossyOccupancy(bool dof, bool stats, bool motion, int blockThreads, size_t ldsBytes, int* treeBlocks);
-hipError_t launchWavefrontGlossy(bool dof, bool stats, bool motion, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
+hipError_t glossyOccupancy(bool dof, bool stats, bool motion, bool transp, int blockThreads, size_t ldsBytes, int* treeBlocks);
+hipError_t launchWavefrontGlossy(bool dof, bool stats, bool motion, bool transp, int treeBlocks, int shadowBlocks, int blockThreads, size_t ldsBytes, hipStream_t stream,
     const DevScene& sc, const DevCamera& cam, const DevFeat& ft, const DevFrame& fr, const WfParams& wp, const WfBuffers& wb, DevCounters* ctr,
     float* out, int minActive, int minActiveShadow, hipEvent_t* marks, int numCU);
 

@@ -170,6 +170,10 @@ def test_motion_blur_on_the_queue_based_renderer():
                                              enableEnvironmentMap=1)),
         (scn, sio.default_camera(w, h), dict(motionBlurSamples=2, movement=0.9, numShadowSamples=1, enableReflections=1, maxRayDepth=3,
                                              enableGlossyReflection=1, numGlossySamples=2, glossyExponent=1.0)),
+        # ... and all of it at once
+        (clear, sio.default_camera(w, h), dict(motionBlurSamples=2, movement=0.5, numShadowSamples=2, enableReflections=1, maxRayDepth=2,
+                                               enableGlossyReflection=1, numGlossySamples=2, glossyExponent=0.5, enableTransparency=1,
+                                               enableEnvironmentMap=1)),
     ]
     batched = {False: [], True: []}  # pixel batches of the small-workspace frames, without and with transparency
     for k, (s, cam, kw) in enumerate(cases):

@@ -174,12 +174,13 @@ def test_jittered_sampling_and_glossy_reflections(ctx):
 
 
 def test_glossy_reflections_on_the_queue_based_renderer():
-    """Glossy reflections without transparency run on the queue-based renderer: a tree kernel walks every pixel's
+    """Glossy reflections run on the queue-based renderer: a tree kernel walks every pixel's
     camera and glossy rays in the recursion's order (the directions are drawn, src/extra.cpp:348-362) and writes the
     hits down, the light samples of all hits go through the same kernels as for mirror reflections, and the combine
     folds the trees.  Against the oracle, and bit for bit against the per-pixel kernel: one to four glossy samples,
     depth caps one to three, several camera rays per pixel, a lens, an environment map (children that leave the
-    scene carry a colour), all three kinds of light, pixel batches (a small workspace), shards."""
+    scene carry a colour), all three kinds of light, pixel batches (a small workspace), shards, and transparency on top
+    (a pass-through child after the glossy ones)."""
     import copy
     scn = copy.deepcopy(common.scene("CornellBox", env_map=True))
     scn.lights = [sio.cornell_parallelogram_light(), sio.point_light((0.2, 0.3, 0.4), (0.6, 0.5, 0.4)),
@@ -217,6 +218,39 @@ def test_glossy_reflections_on_the_queue_based_renderer():
         assert np.array_equal(np.isfinite(images["queues"]), finite), k
         for name in ("queues, small workspace", "per pixel"):
             assert np.array_equal(images["queues"].view(np.uint32), images[name].view(np.uint32)), (k, name)
+    # with transparency on top: a hit that is not opaque has a pass-through child after its glossy children
+    clear = copy.deepcopy(scn)
+    for i, m in enumerate(clear.meshes):
+        m.material["transparency"] = 1.0 if i == 0 else (0.5 if i % 2 else 0.8)  # (one mesh stays opaque)
+    oclear = orc.OracleScene(clear)
+    for k, kw in enumerate([
+        dict(numGlossySamples=2, glossyExponent=0.5, maxRayDepth=2, numShadowSamples=1),
+        dict(numGlossySamples=3, glossyExponent=1.0, maxRayDepth=2, numShadowSamples=2, enableEnvironmentMap=1, numPixelSamples=2),
+        dict(numGlossySamples=1, glossyExponent=0.3, maxRayDepth=3, numShadowSamples=1, enableDepthOfField=1, numDepthOfFieldSamples=2,
+             depthOfFieldDistance=2.5),
+        dict(numGlossySamples=0, glossyExponent=0.5, maxRayDepth=2, numShadowSamples=1),
+        dict(numGlossySamples=2, glossyExponent=0.5, maxRayDepth=2, numShadowSamples=1, enableReflections=0),
+    ]):
+        f = common.features(**dict(dict(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, enableGlossyReflection=1,
+                                        enableNormalInterp=1, enableTransparency=1), **kw))
+        ref, st_o = oclear.render(f, cam, w, h)
+        images = {}
+        for name, opts in (("queues", dict(per_pixel=0)), ("queues, small workspace", dict(per_pixel=0, workspace_bytes=8 << 20)),
+                           ("per pixel", dict(per_pixel=1))):
+            c = _ctx_with(**opts)
+            c.upload_scene(clear)
+            c.set_features(f)
+            img, st = c.render(cam, w, h)
+            c.close()
+            assert st["rays"] == st_o["rays"], ("clear", k, name, st["rays"], st_o["rays"])
+            images[name] = img
+        finite = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(images["queues"]), finite), ("clear", k)
+        if finite.any():
+            maxabs = float(np.abs(images["queues"][finite].astype(np.float64) - ref[finite].astype(np.float64)).max())
+            assert maxabs <= 2e-5, ("clear", k, maxabs)
+        for name in ("queues, small workspace", "per pixel"):
+            assert np.array_equal(images["queues"].view(np.uint32), images[name].view(np.uint32)), ("clear", k, name)
     # shards of the frame, packed, against the per-pixel kernel's
     f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, enableGlossyReflection=1,
                         numGlossySamples=2, glossyExponent=0.5, maxRayDepth=2, numShadowSamples=2, numPixelSamples=2)
