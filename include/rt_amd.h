@@ -189,8 +189,7 @@ void rt_ctx_destroy(rt_ctx* ctx);
  *                           2 (default) the library's own over single primitives, 1 its own over the
  *                           caller's leaves, 0 the caller's inner nodes as they are.  Results do not depend on it.
  *  RT_OPT_PER_PIXEL         1 = every frame on the kernel that walks a pixel in renderRay's own depth-first
- *                           order; 0 (default) = queue-based renderer wherever it applies (everything but glossy
- *                           reflections combined with transparency or with motion blur).  Same bits either way.
+ *                           order; 0 (default) = the queue-based renderer.  Same bits either way: a cross-check.
  *  RT_OPT_STRICT_INTERSECT  1 = rt_intersect_batch replays every ray in the reference's own order of box
  *                           and triangle tests (src/bvh.cpp:245-316).  A cross-check: by default only rays
  *                           are replayed that met equal distances, or whose hit the reference's box routine

@@ -1,7 +1,7 @@
 """Glossy reflections (src/extra.cpp:329-368) at 1920x1080 on the two renderers that take them: the queue-based one
 (tree kernel + shared light-sample kernels) and the per-pixel kernel.  Device frame time (kernel_ms of rt_render_device),
 ray counts, and a bit comparison of the two frames.
-  python tools/time_glossy.py [scene] [glossy samples] [depth cap] [pixel samples] [area light: 0/1]"""
+  python tools/time_glossy.py [scene] [glossy samples] [depth cap] [pixel samples] [area light: 0/1] [transparency of every other mesh, 1 = opaque]"""
 import importlib
 import json
 import os
@@ -25,14 +25,21 @@ def main():
     cap = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     spp = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     area = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    clear = float(sys.argv[6]) if len(sys.argv) > 6 else 1.0
     w, h = 1920, 1080
-    scn = common.scene(name)
+    import copy
+    scn = copy.deepcopy(common.scene(name))
+    if clear != 1.0:
+        for i, m in enumerate(scn.meshes):
+            if i % 2:
+                m.material["transparency"] = clear
     if area:
         scn.lights = [sio.cornell_parallelogram_light()]
     f = common.features(enableShading=1, enableShadows=1, enableReflections=1, shadingModel=2, enableGlossyReflection=1,
-                        numGlossySamples=g, glossyExponent=0.5, maxRayDepth=cap, numPixelSamples=spp, numShadowSamples=4)
+                        numGlossySamples=g, glossyExponent=0.5, maxRayDepth=cap, numPixelSamples=spp, numShadowSamples=4,
+                        enableTransparency=int(clear != 1.0))
     cam = sio.default_camera(w, h)
-    out = {"scene": name, "frame": [w, h], "glossy_samples": g, "depth_cap": cap, "pixel_samples": spp, "area_light": bool(area)}
+    out = {"scene": name, "frame": [w, h], "glossy_samples": g, "depth_cap": cap, "pixel_samples": spp, "area_light": bool(area), "transparency": clear}
     frames = {}
     for label, opts in (("queues", dict(per_pixel=0)), ("per_pixel", dict(per_pixel=1))):
         c = capi.Context(0, **opts)
