@@ -808,6 +808,8 @@ int readStats(rt_ctx* ctx, rt_stats* stats, bool timed)
     HIP_TRY(ctx, hipMemcpy(&c, ctx->lastCounters, debug ? sizeof c : offsetof(DevCounters, waveLog), hipMemcpyDeviceToHost));
     if (debug)
         fprintf(stderr, "[rt_amd] light samples of the last batch left to the replay (their occluder's leaf may be out of the reference's reach): %u\n", c.redo.v);
+    if (debug)
+        fprintf(stderr, "[rt_amd] paths of the last batch handed over to the kernel that follows them by the reference's own walk: %u\n", c.pathRedo.v);
     if (getenv("RT_AMD_DEBUG_COUNTERS") && (c.loopIters[0][2] | c.loopIters[1][2])) {
         // wave iterations of the traversal loop and the mean number of lanes that had work in them
         const char* names[2] = { "path", "shadow" };

@@ -210,6 +210,7 @@ struct DevCounters {
     // wave to find a queue empty raises for the others ([0] path, [1] shadow); cleared before every batch
     HotCounter next, nextShadow, nodes, camQueued, dry[2];
     HotCounter redo; // light samples whose occluder the reference may not have come to (Tracer::surelyReached): entries of WfBuffers::redo
+    HotCounter pathRedo; // camera rays whose path met a hit that takes the reference's own walk to decide: entries of the path kernel's hand-over list
     // counting launches only: iterations of the traversal loop summed over all 64 lanes of
     // every wave (divide by 64 for wave iterations), [0] inner [1] leaf [2] calls of run()
     unsigned long long loopIters[2][3]; // [0] path kernel, [1] shadow kernel

@@ -288,6 +288,26 @@ struct Tracer {
         }
     }
 
+    // One BVHInterface::intersect call answered at once by the reference's own walk over the caller's nodes
+    // (replayReference), not by the traversal loop: for the rays of a path one of whose hits takes that walk to decide
+    // (settleTie), followed to its end by a kernel of its own.  Needs the acceleration structure on and the caller's nodes.
+    __device__ __forceinline__ void launchExact(RayState& r, f3 o, f3 d, float tmax, int kind) const
+    {
+        begin(r, o, d, tmax, kind);
+        const uint2 res = replayReference<MOTION>(sc.refNodes, sc.tris, stk, stride, o.x, o.y, o.z, d.x, d.y, d.z, tmax, MOTION ? &r.mv : nullptr);
+        r.tmax = __uint_as_float(res.x);
+        r.hitPrim = (int)res.y;
+    }
+
+    // Does the finished traversal's answer take the reference's own walk to decide (see settleTie, which makes that
+    // walk on the spot)?  Clears the mark either way.
+    __device__ __forceinline__ bool doubtful(RayState& r) const
+    {
+        const bool d = accel && sc.refNodes != nullptr && (r.tie || (sc.leafBoxes != nullptr && r.hitPrim >= 0 && !surelyReached(r)));
+        r.tie = false;
+        return d;
+    }
+
     // The same for a ray already known to pass entersScene() (acceleration structure on).
     __device__ __forceinline__ void launchInside(RayState& r, f3 o, f3 d, float tmax, int kind) const
     {

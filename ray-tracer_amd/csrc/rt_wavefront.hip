@@ -265,14 +265,33 @@ __global__ __launch_bounds__(256) void cameraKernel(const DevScene sc, const Dev
 #endif
 // MOTION: the queued ray's record carries its time; the ray and the mirror chain behind it meet the copy of the scene
 // moved to that time (Tracer<., true>, RayState::mv).
-template <bool STATS, bool TRANSP, bool MOTION = false>
+// Hits that take the reference's own walk over the caller's nodes to decide (two primitives at one distance, a hit its
+// box routine may have lost: Tracer::settleTie) are one in millions, but the out-of-line function that makes the walk
+// costs the kernel that calls it registers all the time (the compiler keeps what the callee uses free across the
+// call): 1.5-1.9 % of the headline frame, a sixth of a frame with motion blur, measured by leaving the call out.
+// RT_DEFER_TIES=1 is the experiment that tried to have that back: without transparency (a chain of hits, which can be
+// picked up again from its records alone) the kernel makes no such call; a path that meets such a hit is handed over
+// -- its camera ray's index goes on a list (in the memory of WfBuffers::contrib, unused until the light samples are
+// made) -- and the EXACT variant of the kernel, launched behind it over that list, finds where the path stopped from
+// the nodes it left, answers that ray and every later one of the path by the reference's walk (Tracer::launchExact)
+// and writes the rest of the chain.  Bit-equal (every GPU test, 1 200 random configurations), and slower: the handful
+// of walks a frame needs, hidden among thousands of busy waves when made on the spot, stand alone at the end of the
+// path stage and take 0.26 ms there (headline frame 5.70 ms against 5.55).  Off.
+#ifndef RT_DEFER_TIES
+#define RT_DEFER_TIES 0
+#endif
+template <bool STATS, bool TRANSP, bool MOTION = false, bool EXACT = false>
 __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const DevScene sc, const DevFeat ft, const WfParams wp, const WfBuffers wb,
     DevCounters* __restrict__ ctr, int minActive)
 {
+    static_assert(!EXACT || !TRANSP, "a tree of hits is not picked up again from its records");
+    constexpr bool DEFER = RT_DEFER_TIES && !TRANSP && !EXACT;
     extern __shared__ uint32_t stackMem[];
     const Tracer<STATS, MOTION> tracer { sc, ft.accel, (LdsWords)(stackMem + threadIdx.x) };
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = ctr->camQueued.v;
+    const uint32_t total = EXACT ? ctr->pathRedo.v : ctr->camQueued.v;
+    uint32_t* handedOver = reinterpret_cast<uint32_t*>(wb.contrib); // (at most one entry per queued camera ray: 4 B against 12 B per light sample)
+    uint32_t mine = blockIdx.x * blockDim.x + threadIdx.x;           // EXACT: this lane's next entry of the list
     // node slots a wave reserves per atomic: about what its share of the rays will fill, so that a small
     // frame does not leave most of the pool's touched part empty (every slot is a work item further on)
     uint32_t nodeBlock = wp.nodeBlockMax;
@@ -312,11 +331,42 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
         // ---- lanes without a path take the next queued camera ray
         for (int round = 0; round < 2; round++) {
             bool want = !have && !dead;
-            q.fetch(want, item, dead, &ctr->next, &ctr->dry[0], total, lane);
+            if (EXACT) { // (a handful of entries: by position)
+                if (want) {
+                    want = false;
+                    if (mine < total) {
+                        item = handedOver[mine];
+                        mine += gridDim.x * blockDim.x;
+                    } else {
+                        dead = true;
+                    }
+                }
+            } else {
+                q.fetch(want, item, dead, &ctr->next, &ctr->dry[0], total, lane);
+            }
             if (!have && !dead && !want) {
                 const float4 c0 = wb.camRays[2u * (size_t)item + 0], c1 = wb.camRays[2u * (size_t)item + 1];
                 path = __float_as_uint(c0.w);
-                if (MOTION) {
+                if (EXACT) {
+                    // where the path stopped: behind the last node of the chain it left (none: at its camera ray)
+                    if (MOTION)
+                        r.mv = makeMover(c1.w, ft.movement);
+                    f3 o = { c0.x, c0.y, c0.z }, d = { c1.x, c1.y, c1.z };
+                    depth = 0;
+                    prev = -1;
+                    count = 0;
+                    for (int32_t cur = wb.pathHead[path]; cur >= 0 && depth <= kMaxDepth; cur = wb.nodeB[cur].childR) {
+                        prev = cur;
+                        depth++;
+                        count++;
+                    }
+                    if (prev >= 0) {
+                        const float4* a = wb.nodeA + 4u * (size_t)prev;
+                        const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+                        reflectionRay({ a0.x, a0.y, a0.z }, { a1.z, a1.w, a2.x }, { a0.w, a1.x, a1.y }, o, d);
+                    }
+                    tracer.launchExact(r, o, d, kFltMax, K_RADIANCE);
+                } else if (MOTION) {
                     r.mv = makeMover(c1.w, ft.movement);
                     tracer.launch(r, { c0.x, c0.y, c0.z }, { c1.x, c1.y, c1.z }, kFltMax, K_RADIANCE);
                 } else if (c1.w != 0.0f)
@@ -324,15 +374,27 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
                 else
                     tracer.launch(r, { c0.x, c0.y, c0.z }, { c1.x, c1.y, c1.z }, kFltMax, K_RADIANCE);
                 have = true;
-                depth = 0;
-                prev = -1;
+                if (!EXACT) {
+                    depth = 0;
+                    prev = -1;
+                    count = 0;
+                }
                 viaPass = false;
-                count = 0;
                 nWaiting = 0;
             }
             // ---- paths whose ray has finished: record the hit, go on with a child ray or retire
             while (have && !r.active) {
-                tracer.settleTie(r);
+                if (DEFER) {
+                    if (tracer.doubtful(r)) { // the path is handed over as it stands
+                        handedOver[atomicAdd(&ctr->pathRedo.v, 1u)] = item;
+                        if (count == 0)
+                            wb.pathHead[path] = kPathMiss; // (no node yet: says so to whoever picks the path up)
+                        have = false;
+                        break;
+                    }
+                } else if (!EXACT) {
+                    tracer.settleTie(r);
+                }
                 if (sc.nSpheres)
                     tracer.spheres(r);
                 bool childLaunched = false;
@@ -415,7 +477,10 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
                                     waiting[kBlockThreads * nWaiting++] = idx;
                                 f3 o, d;
                                 reflectionRay(h.P, r.d, h.N, o, d);
-                                tracer.launch(r, o, d, kFltMax, K_RADIANCE);
+                                if (EXACT)
+                                    tracer.launchExact(r, o, d, kFltMax, K_RADIANCE);
+                                else
+                                    tracer.launch(r, o, d, kFltMax, K_RADIANCE);
                                 viaPass = false;
                                 childLaunched = true;
                             } else if (wantPass) { // generatePassthroughRay, src/recursive.cpp:98-111
@@ -486,7 +551,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
     __syncthreads();
     if (threadIdx.x == 0) {
         // reflection rays counted here; every camera ray of a real pixel is one intersect call, traced or not
-        unsigned long long all = blockIdx.x == 0 ? (unsigned long long)wp.validPaths : 0ull, shadow = 0ull;
+        unsigned long long all = (!EXACT && blockIdx.x == 0) ? (unsigned long long)wp.validPaths : 0ull, shadow = 0ull;
         for (uint32_t w = 0; w < kBlockWaves; w++)
             all += raySums[w][0], shadow += raySums[w][1];
         if (all)
@@ -495,7 +560,7 @@ __global__ __launch_bounds__(kBlockThreads) RT_PATH_ATTR void pathKernel(const D
             atomicAdd(&ctr->sRays, shadow);
     }
     if (lane == 0) {
-        if (STATS) {
+        if (STATS && !EXACT) {
             atomicAdd(&ctr->inner, ni);
             atomicAdd(&ctr->tris, nt);
             atomicAdd(&ctr->loopIters[0][0], ii);
@@ -1662,6 +1727,15 @@ static ShadowFn pathVariant(bool stats, bool transp, bool motion = false)
         return stats ? pathKernel<true, true> : pathKernel<false, true>;
     return stats ? pathKernel<true, false> : pathKernel<false, false>;
 }
+#if RT_DEFER_TIES
+// the kernel that follows handed-over paths to their end (pathKernel, EXACT)
+static ShadowFn pathExactVariant(bool stats, bool motion)
+{
+    if (motion)
+        return stats ? pathKernel<true, false, true, true> : pathKernel<false, false, true, true>;
+    return stats ? pathKernel<true, false, false, true> : pathKernel<false, false, false, true>;
+}
+#endif
 static ShadowFn shadowVariant(bool stats, bool transp, bool motion = false)
 {
     if (motion && transp)
@@ -1707,6 +1781,10 @@ hipError_t launchWavefront(bool dof, bool stats, bool transp, bool motion, int p
     else
         hipLaunchKernelGGL(cameraKernel<false>, dim3(cb), dim3(256), 0, stream, sc, cam, ft, fr, wp, wb, ctr);
     hipLaunchKernelGGL(pathVariant(stats, transp, motion), dim3(pathBlocks), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActive);
+#if RT_DEFER_TIES
+    if (!transp && ft.accel && sc.refNodes != nullptr) // (no list otherwise)
+        hipLaunchKernelGGL(pathExactVariant(stats, motion), dim3(numCU), dim3(blockThreads), ldsBytes, stream, sc, ft, wp, wb, ctr, minActive);
+#endif
     if (marks)
         (void)hipEventRecord(marks[0], stream);
     const int pb = (int)((nSampleSlots + 255) / 256);
